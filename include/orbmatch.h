@@ -1,0 +1,212 @@
+/*
+ * orbmatch.h -- C ABI of liborbmatch_hip.so: MI355X (gfx950) implementation of the ORB-SLAM2
+ * descriptor-matching hot path (ORB_SLAM2::ORBmatcher).
+ *
+ * The reference has no FFI; its boundary is the C++ class ORBmatcher (ORBmatcher.h:39-257).
+ * Each entry point below is the flat (pointer + size) form of one reference method; the
+ * drop-in C++ class in orbslam2_amd/host/ORBmatcher.{h,cc} flattens the pointer graph, calls
+ * these and re-applies the pointer side effects.  All citations are file:line under the
+ * reference tree.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is borrowed for the duration of the call;
+ *  - return value >= 0 is success (a count where the reference returns one), < 0 is an
+ *    ORBM_E* code; orbm_last_error() returns the text of the last failure on that context;
+ *  - a context (orbm_ctx) is one calling thread's state: device, HIP stream, grow-only device
+ *    workspace, frame table.  The reference matcher is called concurrently from three threads
+ *    (System.cc:112,117); give each thread its own context.  Calls on one context must not
+ *    overlap;
+ *  - "io_on_device": 0 = the index lists and outputs of a batch call are HOST pointers (the
+ *    call stages them and synchronises before returning); 1 = they are DEVICE pointers and the
+ *    call only enqueues work on the context's stream (no allocation-free guarantee: the
+ *    workspace may grow on the first call of a given size).
+ */
+#ifndef ORBMATCH_H
+#define ORBMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ORBmatcher.cc:37-39 */
+#define ORBM_TH_HIGH 100
+#define ORBM_TH_LOW 50
+#define ORBM_HISTO_LENGTH 30
+/* Frame.h:37-38 */
+#define ORBM_GRID_ROWS 48
+#define ORBM_GRID_COLS 64
+#define ORBM_GRID_CELLS (ORBM_GRID_ROWS * ORBM_GRID_COLS)
+#define ORBM_MAX_LEVELS 16
+
+#define ORBM_OK 0
+#define ORBM_EINVAL (-1)  /* bad argument (NULL, negative size, id out of range, stride too small) */
+#define ORBM_EHIP (-2)    /* a HIP runtime call failed; see orbm_last_error */
+#define ORBM_ENOMEM (-3)  /* host or device allocation failed */
+#define ORBM_ELIMIT (-4)  /* input exceeds a documented limit of the kernel */
+
+/* mp_flags bits (per keypoint): state of Frame::mvpMapPoints[i] / KeyFrame::GetMapPoint(i). */
+#define ORBM_MP_PRESENT 1u /* pointer non-NULL */
+#define ORBM_MP_BAD 2u     /* MapPoint::isBad() (MapPoint.cc:315) */
+#define ORBM_MP_OBS 4u     /* MapPoint::Observations() > 0 (MapPoint.cc:212) */
+
+/* query flags for orbm_proj_queries */
+#define ORBM_Q_VALID 1u /* mbTrackInView && !isBad()  (ORBmatcher.cc:69-73) */
+#define ORBM_Q_OBS 2u   /* Observations() > 0 of the query map point (seen by later queries through
+                           F.mvpMapPoints[idx]->Observations(), ORBmatcher.cc:113-115) */
+
+/*
+ * Flat view of what the matcher reads from a Frame / KeyFrame (Frame.h:235-291, KeyFrame.h:232-282).
+ * For a KeyFrame pass min_x..max_y already truncated to int as KeyFrame.cc:49-50 does.
+ */
+typedef struct orbm_frame_view {
+    int32_t n;                  /* N */
+    const uint8_t *desc;        /* mDescriptors, n x 32 bytes, row i = keypoint i (Frame.h:253) */
+    const float *x;             /* mvKeysUn[i].pt.x */
+    const float *y;             /* mvKeysUn[i].pt.y */
+    const float *angle;         /* mvKeysUn[i].angle, degrees */
+    const float *angle_raw;     /* mvKeys[i].angle (ORBmatcher.cc:323 reads mvKeys); NULL => angle */
+    const int32_t *octave;      /* mvKeysUn[i].octave */
+    const float *uright;        /* mvuRight; NULL => all -1 (monocular) */
+    const uint8_t *mp_flags;    /* ORBM_MP_* per keypoint; NULL => all 0 */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float inv_w, inv_h;         /* mfGridElementWidthInv, mfGridElementHeightInv */
+    int32_t n_levels;           /* mnScaleLevels (<= ORBM_MAX_LEVELS) */
+    const float *scale_factors; /* mvScaleFactors[n_levels] */
+    const float *level_sigma2;  /* mvLevelSigma2[n_levels] */
+    /* DBoW2::FeatureVector as CSR: nodes ascending, indices in map order (ORBmatcher.cc:243-254) */
+    int32_t n_nodes;
+    const uint32_t *fv_node;    /* n_nodes node ids, strictly ascending */
+    const uint32_t *fv_off;     /* n_nodes+1 offsets into fv_idx */
+    const uint32_t *fv_idx;     /* keypoint indices */
+} orbm_frame_view;
+
+/* Flat view of the map points handed to SearchByProjection(Frame&, vector<MapPoint*>&, th)
+ * after Frame::isInFrustum filled the tracking fields (Frame.cc:407-412, MapPoint.h:183-198). */
+typedef struct orbm_proj_queries {
+    int32_t n;
+    const uint8_t *desc;    /* MapPoint::GetDescriptor(), n x 32 (MapPoint.cc:453) */
+    const float *proj_x;    /* mTrackProjX */
+    const float *proj_y;    /* mTrackProjY */
+    const float *proj_xr;   /* mTrackProjXR */
+    const int32_t *level;   /* mnTrackScaleLevel */
+    const float *view_cos;  /* mTrackViewCos */
+    const uint8_t *flags;   /* ORBM_Q_* ; NULL => all ORBM_Q_VALID|ORBM_Q_OBS */
+} orbm_proj_queries;
+
+/* Flat view of the queries of the best-1 windowed searches (the three other SearchByProjection
+ * overloads, ORBmatcher.cc:401-542, 1768-1950, 1963-2123).  The host does the float 3-D
+ * projection and the gates that precede GetFeaturesInArea; the device does the window walk,
+ * the Hamming loop, the claims and the rotation histogram. */
+typedef struct orbm_win_queries {
+    int32_t n;
+    const uint8_t *desc;     /* n x 32 */
+    const float *u;          /* window centre */
+    const float *v;
+    const float *radius;     /* window half size (already th*scale) */
+    const int32_t *min_level;/* level arguments of GetFeaturesInArea / the [l-1,l] octave filter */
+    const int32_t *max_level;
+    const float *ur;         /* u - bf*invz for the stereo gate; NULL => gate off */
+    const float *angle;      /* query keypoint angle for the rotation histogram; NULL => no histogram */
+    const uint8_t *flags;    /* ORBM_Q_VALID (query passed the host gates), ORBM_Q_OBS */
+} orbm_win_queries;
+
+typedef struct orbm_ctx orbm_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+orbm_ctx *orbm_create(int device);           /* NULL on failure (orbm_last_error(NULL) has the text) */
+void orbm_destroy(orbm_ctx *ctx);
+const char *orbm_last_error(const orbm_ctx *ctx);
+int orbm_set_stream(orbm_ctx *ctx, void *hip_stream); /* adopt a caller stream (NULL = own stream) */
+int orbm_synchronize(orbm_ctx *ctx);
+int orbm_device_info(orbm_ctx *ctx, int32_t *n_cu, int32_t *clock_khz, char *name, int name_len);
+
+/* ---- device-resident Frame / KeyFrame storage (Frame.h:253,267,249; KeyFrame.h:232,236,282) --
+ * Uploads descriptors (packed 32-byte rows), keypoint SoA, FeatureVector CSR and builds the
+ * 64x48 grid-cell CSR ON THE DEVICE with the round() rule of Frame::PosInGrid
+ * (Frame.cc:278-298, 506-519).  out_ids receive small integer handles. */
+int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views, int32_t *out_ids);
+int orbm_frames_free(orbm_ctx *ctx, int n_frames, const int32_t *ids);
+/* replaces mp_flags of one frame (map points change while descriptors do not) */
+int orbm_frame_set_mp_flags(orbm_ctx *ctx, int32_t id, const uint8_t *mp_flags);
+/* copies the device-built grid back: cell_off[ORBM_GRID_CELLS+1], cell_idx[n]; cell = ix*48+iy */
+int orbm_frame_grid_download(orbm_ctx *ctx, int32_t id, uint32_t *cell_off, uint32_t *cell_idx);
+
+int orbm_proj_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *sets, int32_t *out_ids);
+int orbm_win_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_win_queries *sets, int32_t *out_ids);
+int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
+
+/* ---- a1: ORBmatcher::DescriptorDistance (ORBmatcher.cc:2184-2200), n independent pairs ---- */
+int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist,
+                          int io_on_device);
+
+/* ---- BASELINE config 2: brute-force 2-NN + threshold + ratio test over keyframe pairs --------
+ * For pair p and every row i of frame_a[p]: scan all rows j of frame_b[p] in ascending j with the
+ * strict-< best / second-best update of ORBmatcher.cc:290-300, accept iff best <= th and
+ * (float)best < ratio*(float)second (ORBmatcher.cc:304-308).
+ * match[p*stride+i] = j or -1; best_d / second_d (nullable) get the raw distances (256 = none);
+ * counts[p] = accepted rows.  stride >= max n of the a-frames. */
+int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
+                     float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
+                     int32_t *second_d, int32_t *counts, int io_on_device);
+
+/* ---- a7 / a8: SearchByBoW (ORBmatcher.cc:218-385 and 703-854), batched over pairs -------------
+ * variant 0 = (KeyFrame*, Frame&): a = KF, b = F; match[p*stride + idxF] = idxKF whose map point
+ *             is assigned to F's keypoint, or -1 (vpMapPointMatches, ORBmatcher.cc:312).
+ * variant 1 = (KeyFrame*, KeyFrame*): match[p*stride + idx1] = idx2 or -1 (vpMatches12, :798).
+ * Validity comes from the frames' mp_flags.  counts[p] = returned nmatches.
+ * stride >= n of every b-frame (variant 0) / a-frame (variant 1). */
+int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
+                          const int32_t *frame_b, float ratio, int check_ori, int32_t stride,
+                          int32_t *match, int32_t *counts, int io_on_device);
+
+/* ---- a9: SearchForTriangulation (ORBmatcher.cc:868-1093), batched over pairs ------------------
+ * f12: n_pairs x 9 row-major F12; epipole: n_pairs x 2 (ex, ey) of ORBmatcher.cc:883-884 (the
+ * 3-D pose arithmetic stays on the host).  match12[p*stride + idx1] = idx2 or -1. */
+int orbm_search_triang_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a,
+                             const int32_t *frame_b, const float *f12, const float *epipole,
+                             int only_stereo, int check_ori, int32_t stride, int32_t *match12,
+                             int32_t *counts, int io_on_device);
+
+/* ---- a6: SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:57-166) ------
+ * Instance k matches query set qset[k] into frame frame[k].  slot_flags (n_inst x stride bytes of
+ * ORBM_MP_*, nullable => the frames' own mp_flags) is the initial state of the slot vector the
+ * method reads and writes (F.mvpMapPoints; skip iff PRESENT and OBS, ORBmatcher.cc:113-115).
+ * owner[k*stride + idx] = index of the query whose map point ends up in F.mvpMapPoints[idx]
+ * (last writer), or -1 if the call did not write the slot.  counts[k] = returned nmatches. */
+int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
+                                  float th, float ratio, const uint8_t *slot_flags, int32_t stride,
+                                  int32_t *owner, int32_t *counts, int io_on_device);
+
+/* ---- a11: the best-1 windowed overloads, one kernel, three modes -----------------------------
+ * mode 0 = (Frame& Cur, const Frame& Last, th, bMono)  ORBmatcher.cc:1768-1950: Frame grid with level
+ *          arguments, slot skipped iff PRESENT and OBS, stereo gate fabs(ur-uRight) > radius,
+ *          accept best <= dist_th (TH_HIGH), rotation histogram pushes the slot;
+ * mode 1 = (Frame& Cur, KeyFrame*, sAlreadyFound, th, ORBdist) :1963-2123: slot skipped iff PRESENT,
+ *          accept best <= dist_th (ORBdist), rotation histogram pushes the slot;
+ * mode 2 = (KeyFrame*, Scw, vpPoints, vpMatched, th) :401-542: KeyFrame grid (no level argument,
+ *          KeyFrame.cc:766-812) then octave in [min_level,max_level], slot skipped iff PRESENT,
+ *          accept best <= dist_th (TH_LOW), no histogram.
+ * slot_flags: as for orbm_search_proj_points_batch (CurrentFrame.mvpMapPoints / vpMatched).
+ * owner[k*stride + idx] = query index written to the slot and surviving the rotation filter, else -1. */
+int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame,
+                             const int32_t *qset, int dist_th, int check_ori,
+                             const uint8_t *slot_flags, int32_t stride, int32_t *owner,
+                             int32_t *counts, int io_on_device);
+
+/* ---- a5: SearchForInitialization (ORBmatcher.cc:562-689) --------------------------------------
+ * prev_xy: n1 x 2 floats, vbPrevMatched, in/out (:684-686); matches12: n1 ints, -1 = none.
+ * Host pointers.  Returns nmatches. */
+int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, float *prev_xy, int window,
+                     float ratio, int check_ori, int32_t *matches12);
+
+/* ---- measurement helper (K0 of SURVEY appendix B): sustained v_xor_b32 + v_bcnt_u32_b32 rate ---
+ * Runs `iters` unrolled xor+bcnt pairs per lane on every SIMD and returns lane-ops/s in *rate. */
+int orbm_popcount_peak(orbm_ctx *ctx, int iters, double *lane_ops_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBMATCH_H */

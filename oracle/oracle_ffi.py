@@ -1,0 +1,159 @@
+"""ctypes binding of oracle/liborb_oracle.so (the CPU restatement; TEST INFRASTRUCTURE ONLY).
+
+Importable only from tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke(); nothing under
+orbslam2_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from orbslam2_amd.views import CFrameView, CProjQueries, CWinQueries, GRID_CELLS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liborb_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "orb_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p, i32p, u32p, f32p = (C.POINTER(t) for t in (C.c_uint8, C.c_int32, C.c_uint32, C.c_float))
+        u64p = C.POINTER(C.c_uint64)
+        FV, PQ, WQ = C.POINTER(CFrameView), C.POINTER(CProjQueries), C.POINTER(CWinQueries)
+        L.orc_set_popcnt.argtypes = [C.c_int]
+        L.orc_hamming256.argtypes = [u8p, u8p]
+        L.orc_hamming256_popcnt.argtypes = [u8p, u8p]
+        L.orc_three_maxima.argtypes = [i32p, C.c_int, i32p]
+        L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
+        L.orc_build_grid.argtypes = [FV, u32p, u32p]
+        L.orc_features_in_area.argtypes = [FV, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, i32p]
+        L.orc_bf2nn.argtypes = [FV, FV, C.c_float, C.c_int, i32p, i32p, i32p, u64p]
+        L.orc_search_bow.argtypes = [C.c_int, FV, FV, C.c_float, C.c_int, i32p, u64p]
+        L.orc_search_triang.argtypes = [FV, FV, f32p, f32p, C.c_int, C.c_int, i32p, u64p]
+        L.orc_search_proj_points.argtypes = [FV, PQ, C.c_float, C.c_float, u8p, i32p, u64p]
+        L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
+        L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
+        L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def set_popcnt(on: bool):
+    lib().orc_set_popcnt(int(on))
+
+
+def hamming256(a: np.ndarray, b: np.ndarray, popcnt=False) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    f = lib().orc_hamming256_popcnt if popcnt else lib().orc_hamming256
+    return int(f(_p(a, C.c_uint8), _p(b, C.c_uint8)))
+
+
+def three_maxima(sizes) -> tuple:
+    s = np.ascontiguousarray(sizes, np.int32)
+    out = np.zeros(3, np.int32)
+    lib().orc_three_maxima(_p(s, C.c_int32), len(s), _p(out, C.c_int32))
+    return tuple(int(v) for v in out)
+
+
+def rot_bin(a1: float, a2: float) -> int:
+    return int(lib().orc_rot_bin(a1, a2))
+
+
+def build_grid(f):
+    off = np.zeros(GRID_CELLS + 1, np.uint32)
+    idx = np.zeros(max(f.n, 1), np.uint32)
+    v = f.view()
+    n = lib().orc_build_grid(C.byref(v), _p(off, C.c_uint32), _p(idx, C.c_uint32))
+    return off, idx[:n]
+
+
+def features_in_area(f, x, y, r, min_level=-1, max_level=-1, kf_mode=False):
+    out = np.zeros(max(f.n, 1), np.int32)
+    v = f.view()
+    n = lib().orc_features_in_area(C.byref(v), x, y, r, min_level, max_level, int(kf_mode), _p(out, C.c_int32))
+    return out[:n].copy()
+
+
+def bf2nn(a, b, ratio, th):
+    match = np.zeros(max(a.n, 1), np.int32)
+    bd = np.zeros(max(a.n, 1), np.int32)
+    sd = np.zeros(max(a.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    va, vb = a.view(), b.view()
+    cnt = lib().orc_bf2nn(C.byref(va), C.byref(vb), ratio, th, _p(match, C.c_int32), _p(bd, C.c_int32),
+                          _p(sd, C.c_int32), C.byref(ncmp))
+    return int(cnt), match[:a.n], bd[:a.n], sd[:a.n], int(ncmp.value)
+
+
+def search_bow(variant, a, b, ratio, check_ori):
+    n_out = b.n if variant == 0 else a.n
+    match = np.zeros(max(n_out, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    va, vb = a.view(), b.view()
+    cnt = lib().orc_search_bow(variant, C.byref(va), C.byref(vb), ratio, int(check_ori), _p(match, C.c_int32),
+                               C.byref(ncmp))
+    return int(cnt), match[:n_out], int(ncmp.value)
+
+
+def search_triang(a, b, f12, epipole, only_stereo, check_ori):
+    match = np.zeros(max(a.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    f12 = np.ascontiguousarray(f12, np.float32)
+    ep = np.ascontiguousarray(epipole, np.float32)
+    va, vb = a.view(), b.view()
+    cnt = lib().orc_search_triang(C.byref(va), C.byref(vb), _p(f12, C.c_float), _p(ep, C.c_float),
+                                  int(only_stereo), int(check_ori), _p(match, C.c_int32), C.byref(ncmp))
+    return int(cnt), match[:a.n], int(ncmp.value)
+
+
+def search_proj_points(f, q, th, ratio, slot_flags=None):
+    owner = np.zeros(max(f.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    sf = None if slot_flags is None else np.ascontiguousarray(slot_flags, np.uint8)
+    vf, vq = f.view(), q.view()
+    cnt = lib().orc_search_proj_points(C.byref(vf), C.byref(vq), th, ratio, _p(sf, C.c_uint8),
+                                       _p(owner, C.c_int32), C.byref(ncmp))
+    return int(cnt), owner[:f.n], int(ncmp.value)
+
+
+def search_window(mode, f, q, dist_th, check_ori, slot_flags=None):
+    owner = np.zeros(max(f.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    sf = None if slot_flags is None else np.ascontiguousarray(slot_flags, np.uint8)
+    vf, vq = f.view(), q.view()
+    cnt = lib().orc_search_window(mode, C.byref(vf), C.byref(vq), dist_th, int(check_ori), _p(sf, C.c_uint8),
+                                  _p(owner, C.c_int32), C.byref(ncmp))
+    return int(cnt), owner[:f.n], int(ncmp.value)
+
+
+def search_init(f1, f2, prev_xy, window, ratio, check_ori):
+    prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    v1, v2 = f1.view(), f2.view()
+    cnt = lib().orc_search_init(C.byref(v1), C.byref(v2), _p(prev, C.c_float), window, ratio, int(check_ori),
+                                _p(m12, C.c_int32), C.byref(ncmp))
+    return int(cnt), m12[:f1.n], prev, int(ncmp.value)
+
+
+def predict_scale(max_distance, current_dist, log_scale_factor, n_levels) -> int:
+    return int(lib().orc_predict_scale(max_distance, current_dist, log_scale_factor, n_levels))

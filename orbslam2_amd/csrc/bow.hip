@@ -1,0 +1,289 @@
+// bow.hip -- BoW-node-grouped matching: SearchByBoW (a7: ORBmatcher.cc:218-385, a8: :703-854) and
+// SearchForTriangulation (a9: :868-1093), batched over keyframe pairs.
+//
+// One 256-thread workgroup per pair.  A feature index lives in exactly one node of its FeatureVector,
+// so the reference's "already matched" claims (vpMapPointMatches[idxF] / vbMatched2) only couple queries
+// of the SAME node: (pair, node) groups are independent.  Each wavefront takes common nodes (found by
+// binary search of the a-side node id in the b-side node array == the lower_bound merge walk of
+// :248-352), walks that node's queries IN ORDER, spreads the node's candidates over its 64 lanes and
+// reduces (best, second) over lanes with key = (dist << 16) | position-in-node so that the lowest
+// position wins ties exactly like the reference's strict-< scan.  The first 64 candidates of a node
+// stay in registers for all of its queries.  Ratio test, rotation histogram, ComputeThreeMaxima and
+// the erase pass run in the same launch.
+#include <string.h>
+#include <algorithm>
+#include "orbm_internal.h"
+
+namespace {
+
+constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
+constexpr int MAX_N = 65536;
+
+__device__ __forceinline__ void load_row(const uint32_t *desc, int idx, uint32_t (&r)[8]) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)idx;
+    const uint4 lo = p[0], hi = p[1];
+    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+}
+
+// merge two sorted (best <= second) key pairs across lanes; after the butterfly every lane holds the result
+__device__ __forceinline__ void wave_top2(uint32_t &best, uint32_t &second) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t ob = __shfl_xor(best, off, 64), os = __shfl_xor(second, off, 64);
+        const uint32_t nb = min(best, ob);
+        second = min(max(best, ob), min(second, os));
+        best = nb;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ int find_node(const uint32_t *nodes, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nodes[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && nodes[lo] == key) ? lo : -1;
+}
+
+// ORBmatcher.cc:179-206
+__device__ __forceinline__ bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, float sigma2,
+                                                         const float *F12) {
+    const float a = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[0]), __fmul_rn(y1, F12[3])), F12[6]);
+    const float b = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[1]), __fmul_rn(y1, F12[4])), F12[7]);
+    const float c = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[2]), __fmul_rn(y1, F12[5])), F12[8]);
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
+    const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    if (den == 0) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    return (double)dsqr < __dmul_rn(3.84, (double)sigma2);
+}
+
+// MODE 0: a7 (KF -> F), 1: a8 (KF -> KF), 2: a9 (triangulation)
+template <int MODE>
+__global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+                                                  const int32_t *__restrict__ fb, float ratio, int check_ori,
+                                                  int only_stereo, const float *__restrict__ f12all,
+                                                  const float *__restrict__ epiall, int stride,
+                                                  int32_t *__restrict__ match_all, int32_t *__restrict__ counts) {
+    __shared__ uint32_t claimed[MAX_N / 32];  // bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
+    __shared__ int hist[ORBM_HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int nmatches;
+    const int p = xcd_remap(blockIdx.x, gridDim.x);
+    const FrameDev &A = table[fa[p]];
+    const FrameDev &B = table[fb[p]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nOut = MODE == 0 ? B.n : A.n;
+    int32_t *match = match_all + (size_t)p * stride;
+    for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    if (MODE != 2)
+        for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
+    if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) nmatches = 0;
+    __syncthreads();
+
+    const float *angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
+    float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float ex = 0.f, ey = 0.f;
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) F12[i] = f12all[(size_t)p * 9 + i];
+        ex = epiall[2 * p]; ey = epiall[2 * p + 1];
+    }
+
+    int my_matches = 0;  // wave-uniform, counted on lane 0
+    for (int ia = wave; ia < A.n_nodes; ia += 4) {
+        const int ib = find_node(B.fv_node, B.n_nodes, A.fv_node[ia]);
+        if (ib < 0) continue;
+        const uint32_t offA = A.fv_off[ia], nA = A.fv_off[ia + 1] - offA;
+        const uint32_t offB = B.fv_off[ib], nB = B.fv_off[ib + 1] - offB;
+        if (nA == 0 || nB == 0) continue;
+        // first chunk of candidates stays in registers for every query of the node
+        uint32_t c0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int idxB0 = -1;
+        bool ok0 = false;           // static candidate gates
+        float x2 = 0, y2 = 0; int oct2 = 0; bool st2 = false;
+        if ((uint32_t)lane < nB) {
+            idxB0 = (int)B.fv_idx[offB + lane];
+            load_row(B.desc, idxB0, c0);
+            const uint8_t fl = B.mp_flags[idxB0];
+            if (MODE == 0) ok0 = true;
+            if (MODE == 1) ok0 = (fl & ORBM_MP_PRESENT) && !(fl & ORBM_MP_BAD);          // :766-770
+            if (MODE == 2) {
+                st2 = B.uright[idxB0] >= 0;
+                ok0 = !(fl & ORBM_MP_PRESENT) && (!only_stereo || st2);                  // :970, :979-981
+                x2 = B.x[idxB0]; y2 = B.y[idxB0]; oct2 = B.octave[idxB0];
+            }
+        }
+        for (uint32_t qa = 0; qa < nA; qa++) {
+            const int idxA = (int)A.fv_idx[offA + qa];
+            const uint8_t fA = A.mp_flags[idxA];
+            bool st1 = false;
+            if (MODE == 2) {
+                if (fA & ORBM_MP_PRESENT) continue;                                       // :932
+                st1 = A.uright[idxA] >= 0;
+                if (only_stereo && !st1) continue;                                        // :939-941
+            } else {
+                if (!(fA & ORBM_MP_PRESENT) || (fA & ORBM_MP_BAD)) continue;              // :263-267 / :746-749
+            }
+            uint32_t q[8];
+            load_row(A.desc, idxA, q);
+            const float x1 = MODE == 2 ? A.x[idxA] : 0.f, y1 = MODE == 2 ? A.y[idxA] : 0.f;
+            uint32_t best = INITKEY, second = INITKEY;
+            for (uint32_t cb = 0; cb < nB; cb += 64) {
+                const uint32_t c = cb + lane;
+                if (c >= nB) continue;
+                uint32_t cd[8];
+                int idxB; bool ok; float cx2, cy2; int coct2; bool cst2;
+                if (cb == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) cd[i] = c0[i];
+                    idxB = idxB0; ok = ok0; cx2 = x2; cy2 = y2; coct2 = oct2; cst2 = st2;
+                } else {
+                    idxB = (int)B.fv_idx[offB + c];
+                    load_row(B.desc, idxB, cd);
+                    const uint8_t fl = B.mp_flags[idxB];
+                    ok = true; cx2 = cy2 = 0; coct2 = 0; cst2 = false;
+                    if (MODE == 1) ok = (fl & ORBM_MP_PRESENT) && !(fl & ORBM_MP_BAD);
+                    if (MODE == 2) {
+                        cst2 = B.uright[idxB] >= 0;
+                        ok = !(fl & ORBM_MP_PRESENT) && (!only_stereo || cst2);
+                        cx2 = B.x[idxB]; cy2 = B.y[idxB]; coct2 = B.octave[idxB];
+                    }
+                }
+                if (!ok) continue;
+                if (MODE != 2 && ((claimed[idxB >> 5] >> (idxB & 31)) & 1u)) continue;    // :282 / :766
+                const uint32_t d = hamming256(q, cd);
+                if (MODE == 2) {
+                    if (d > ORBM_TH_LOW) continue;                                        // :993 (first half)
+                    if (!st1 && !cst2) {
+                        const float dex = __fsub_rn(ex, cx2), dey = __fsub_rn(ey, cy2);
+                        if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, B.sf[coct2])) continue;  // :1007
+                    }
+                    if (!check_dist_epipolar_line(x1, y1, cx2, cy2, B.sigma2[coct2], F12)) continue;  // :1014
+                    // "dist > bestDist -> skip" makes an equal distance REPLACE: lowest dist, LAST position wins
+                    best = min(best, (d << 16) | (0xFFFFu - c));
+                } else {
+                    const uint32_t key = (d << 16) | c;
+                    second = umed3(best, second, key);
+                    best = min(best, key);
+                }
+            }
+            if (MODE == 2) {
+                best = wave_min(best);
+                if (best != INITKEY) {                                                    // bestIdx2 >= 0  (:1021)
+                    const uint32_t pos = 0xFFFFu - (best & 0xFFFFu);
+                    const int idx2 = (int)B.fv_idx[offB + pos];
+                    if (lane == 0) {
+                        match[idxA] = idx2;
+                        if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], B.angle[idx2])], 1);
+                        my_matches++;
+                    }
+                }
+            } else {
+                wave_top2(best, second);
+                const int bd = (int)(best >> 16), sd = (int)(second >> 16);
+                const bool pass = MODE == 0 ? (bd <= ORBM_TH_LOW) : (bd < ORBM_TH_LOW);   // :304 / :792
+                if (pass && (float)bd < __fmul_rn(ratio, (float)sd)) {                     // :308 / :796
+                    const int idxBbest = (int)B.fv_idx[offB + (best & 0xFFFFu)];
+                    if (lane == 0) {
+                        atomicOr(&claimed[idxBbest >> 5], 1u << (idxBbest & 31));          // :312 / :799
+                        if (MODE == 0) match[idxBbest] = idxA; else match[idxA] = idxBbest;
+                        if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[idxBbest])], 1);
+                        my_matches++;
+                    }
+                    // the claim must be visible to this wave's next query (same node => same wave)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (lane == 0 && my_matches) atomicAdd(&nmatches, my_matches);
+    __syncthreads();
+    if (check_ori) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        int removed = 0;
+        for (int i = tid; i < nOut; i += 256) {
+            const int m = match[i];
+            if (m < 0) continue;
+            const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
+            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+            if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }        // :368-381 etc.
+        }
+        if (removed) atomicSub(&nmatches, removed);
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = nmatches;
+}
+
+int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, const int32_t *frame_b, float ratio,
+               int check_ori, int only_stereo, const float *f12, const float *epipole, int32_t stride,
+               int32_t *match, int32_t *counts, int io_on_device, const char *who) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_pairs < 0 || (n_pairs > 0 && (!frame_a || !frame_b || !match || !counts)) || stride < 0 ||
+        (mode == 2 && n_pairs > 0 && (!f12 || !epipole)))
+        return orbm_fail(ctx, ORBM_EINVAL, "%s: null argument or negative size", who);
+    if (n_pairs == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!io_on_device) {
+        int rc = orbm_check_frames(ctx, n_pairs, frame_a, "frame_a");
+        if (!rc) rc = orbm_check_frames(ctx, n_pairs, frame_b, "frame_b");
+        if (rc) return rc;
+        for (int p = 0; p < n_pairs; p++) {
+            const int need = mode == 0 ? ctx->h_frames[frame_b[p]].n : ctx->h_frames[frame_a[p]].n;
+            if (need > stride) return orbm_fail(ctx, ORBM_EINVAL, "%s: stride %d < %d rows needed by pair %d", who, stride, need, p);
+        }
+    }
+    const size_t out_elems = (size_t)n_pairs * stride;
+    IoStage io(ctx, io_on_device);
+    if (!io_on_device) {
+        int rc = orbm_ws_reserve(ctx, (size_t)n_pairs * (12 + 44) + out_elems * 4 + 8192);
+        if (rc) return rc;
+    }
+    const void *dfa, *dfb, *df12 = nullptr, *dep = nullptr; void *dm, *dc;
+    int rc;
+    if ((rc = io.in(frame_a, (size_t)n_pairs * 4, &dfa)) || (rc = io.in(frame_b, (size_t)n_pairs * 4, &dfb)) ||
+        (rc = io.in(f12, (size_t)n_pairs * 36, &df12)) || (rc = io.in(epipole, (size_t)n_pairs * 8, &dep)) ||
+        (rc = io.out(match, out_elems * 4, &dm)) || (rc = io.out(counts, (size_t)n_pairs * 4, &dc)))
+        return rc;
+    if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
+    dim3 grid(n_pairs), block(256);
+#define LAUNCH(M)                                                                                              \
+    hipLaunchKernelGGL(bow_kernel<M>, grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,        \
+                       (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
+                       stride, (int32_t *)dm, (int32_t *)dc)
+    if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
+#undef LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
+}
+
+}  // namespace
+
+extern "C" int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
+                                     const int32_t *frame_b, float ratio, int check_ori, int32_t stride,
+                                     int32_t *match, int32_t *counts, int io_on_device) {
+    if (ctx && variant != 0 && variant != 1) return orbm_fail(ctx, ORBM_EINVAL, "search_bow_batch: variant must be 0 or 1");
+    return launch_bow(ctx, variant, n_pairs, frame_a, frame_b, ratio, check_ori, 0, nullptr, nullptr, stride, match,
+                      counts, io_on_device, "search_bow_batch");
+}
+
+extern "C" int orbm_search_triang_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
+                                        const float *f12, const float *epipole, int only_stereo, int check_ori,
+                                        int32_t stride, int32_t *match12, int32_t *counts, int io_on_device) {
+    return launch_bow(ctx, 2, n_pairs, frame_a, frame_b, 1.0f, check_ori, only_stereo, f12, epipole, stride, match12,
+                      counts, io_on_device, "search_triang_batch");
+}

@@ -1,0 +1,564 @@
+// ctx.hip -- context, device-resident frame / query-set storage, grid-cell index build (a15, a16),
+// batched DescriptorDistance (a1) and the popcount-rate micro-kernel (K0).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "orbm_internal.h"
+
+static thread_local std::string g_create_err;
+
+int orbm_fail(orbm_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return ORBM_OK;
+    if (ctx->ws) HIPCHK(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr; ctx->ws_bytes = 0;
+    size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+    HIPCHK(ctx, hipMalloc(&ctx->ws, cap));
+    ctx->ws_bytes = cap;
+    return ORBM_OK;
+}
+
+int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws2_bytes) return ORBM_OK;
+    if (ctx->ws2) HIPCHK(ctx, hipFree(ctx->ws2));
+    ctx->ws2 = nullptr; ctx->ws2_bytes = 0;
+    size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+    HIPCHK(ctx, hipMalloc(&ctx->ws2, cap));
+    ctx->ws2_bytes = cap;
+    return ORBM_OK;
+}
+
+void *IoStage::carve(size_t bytes) {
+    void *p = (char *)ctx->ws + used;
+    used += align_up(bytes, 256);
+    return p;
+}
+
+int IoStage::in(const void *p, size_t bytes, const void **devp) {
+    if (dev || p == nullptr) { *devp = p; return ORBM_OK; }
+    void *d = carve(bytes);
+    if (used > ctx->ws_bytes) return orbm_fail(ctx, ORBM_ENOMEM, "I/O staging workspace overflow");
+    HIPCHK(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *devp = d;
+    return ORBM_OK;
+}
+
+int IoStage::out(void *p, size_t bytes, void **devp) {
+    if (dev || p == nullptr) { *devp = p; return ORBM_OK; }
+    void *d = carve(bytes);
+    if (used > ctx->ws_bytes) return orbm_fail(ctx, ORBM_ENOMEM, "I/O staging workspace overflow");
+    outs.push_back({p, d, bytes});
+    *devp = d;
+    return ORBM_OK;
+}
+
+int IoStage::finish() {
+    if (dev) return ORBM_OK;
+    for (auto &o : outs) HIPCHK(ctx, hipMemcpyAsync(o.host, o.devp, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBM_OK;
+}
+
+int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what) {
+    for (int i = 0; i < n; i++) {
+        int32_t id = ids[i];
+        if (id < 0 || (size_t)id >= ctx->h_frames.size() || ctx->frame_arena[id] < 0)
+            return orbm_fail(ctx, ORBM_EINVAL, "%s[%d] = %d is not a live frame id", what, i, id);
+    }
+    return ORBM_OK;
+}
+
+int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what) {
+    for (int i = 0; i < n; i++) {
+        int32_t id = ids[i];
+        if (id < 0 || (size_t)id >= ctx->h_qsets.size() || ctx->qset_arena[id] < 0 || ctx->h_qsets[id].kind != kind)
+            return orbm_fail(ctx, ORBM_EINVAL, "%s[%d] = %d is not a live query-set id of the right kind", what, i, id);
+    }
+    return ORBM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid-cell index build: Frame::AssignFeaturesToGrid + Frame::PosInGrid (Frame.cc:278-298, 506-519).
+// One workgroup per frame: LDS histogram over the 3072 cells, block scan, scatter, then every cell's
+// short list is put in ascending keypoint order (the reference appends in index order).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pos_in_grid(const FrameDev &f, int i) {
+    const int posX = (int)roundf(__fmul_rn(__fsub_rn(f.x[i], f.min_x), f.inv_w));
+    const int posY = (int)roundf(__fmul_rn(__fsub_rn(f.y[i], f.min_y), f.inv_h));
+    if (posX < 0 || posX >= ORBM_GRID_COLS || posY < 0 || posY >= ORBM_GRID_ROWS) return -1;
+    return posX * ORBM_GRID_ROWS + posY;
+}
+
+__global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restrict__ table,
+                                                         const int32_t *__restrict__ ids) {
+    __shared__ uint32_t cnt[ORBM_GRID_CELLS];
+    __shared__ uint32_t part[256];
+    const FrameDev &f = table[ids[blockIdx.x]];
+    const int tid = threadIdx.x;
+    const int n = f.n;
+    for (int c = tid; c < ORBM_GRID_CELLS; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = pos_in_grid(f, i);
+        if (c >= 0) atomicAdd(&cnt[c], 1u);
+    }
+    __syncthreads();
+    // exclusive scan: 12 consecutive cells per thread
+    constexpr int PER = ORBM_GRID_CELLS / 256;
+    uint32_t loc[PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { loc[k] = s; s += cnt[tid * PER + k]; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; t++) { uint32_t v = part[t]; part[t] = run; run += v; }
+        f.cell_off[ORBM_GRID_CELLS] = run;
+    }
+    __syncthreads();
+    const uint32_t base = part[tid];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t o = base + loc[k];
+        f.cell_off[tid * PER + k] = o;
+        cnt[tid * PER + k] = o;  // becomes the scatter cursor
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = pos_in_grid(f, i);
+        if (c >= 0) f.cell_idx[atomicAdd(&cnt[c], 1u)] = (uint32_t)i;
+    }
+    __syncthreads();
+    __threadfence_block();
+    // ascending order inside each cell (lists are short: ~0.65 keypoints per cell at n=2000)
+    for (int c = tid; c < ORBM_GRID_CELLS; c += 256) {
+        const uint32_t b = f.cell_off[c], e = cnt[c];
+        for (uint32_t i = b + 1; i < e; i++) {
+            const uint32_t v = f.cell_idx[i];
+            uint32_t j = i;
+            while (j > b && f.cell_idx[j - 1] > v) { f.cell_idx[j] = f.cell_idx[j - 1]; j--; }
+            f.cell_idx[j] = v;
+        }
+    }
+}
+
+// a1: n independent 256-bit distances; one lane per pair, rows read as two 16-byte loads.
+__global__ __launch_bounds__(256) void hamming_pairs_kernel(int n, const uint4 *__restrict__ a,
+                                                            const uint4 *__restrict__ b, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 a0 = a[2 * i], a1 = a[2 * i + 1], b0 = b[2 * i], b1 = b[2 * i + 1];
+    const uint32_t x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const uint32_t y[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    out[i] = (int32_t)hamming256(x, y);
+}
+
+// K0: sustained xor + bcnt(accumulate) issue rate.  Every lane runs `iters` rounds of 8 independent
+// xor/bcnt pairs (the shape of one DescriptorDistance); the result is stored so nothing is dead.
+__global__ __launch_bounds__(256) void popcount_peak_kernel(int iters, uint32_t seed, uint32_t *__restrict__ sink) {
+    uint32_t q[8], acc[4] = {0, 0, 0, 0};
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = (t + 1) * 2654435761u + i * 40503u + seed;
+    acc[0] = seed; acc[1] = seed * 3u; acc[2] = seed * 5u; acc[3] = seed * 7u;
+    for (int it = 0; it < iters; it++) {
+        // 8 steps x 4 independent (v_xor_b32 + v_bcnt_u32_b32 accumulate) pairs, all operands in VGPRs;
+        // each pair reads a neighbour accumulator so that nothing is loop-invariant.
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t b0 = acc[1], b1 = acc[2], b2 = acc[3], b3 = acc[0];
+            acc[0] = __builtin_popcount(q[i] ^ b0) + acc[0];
+            acc[1] = __builtin_popcount(q[i] ^ b1) + acc[1];
+            acc[2] = __builtin_popcount(q[i] ^ b2) + acc[2];
+            acc[3] = __builtin_popcount(q[i] ^ b3) + acc[3];
+        }
+    }
+    sink[t] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+extern "C" {
+
+orbm_ctx *orbm_create(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        orbm_fail(nullptr, ORBM_EHIP, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        orbm_fail(nullptr, ORBM_EINVAL, "device %d out of range (have %d)", device, ndev);
+        return nullptr;
+    }
+    orbm_ctx *ctx = new (std::nothrow) orbm_ctx();
+    if (!ctx) { orbm_fail(nullptr, ORBM_ENOMEM, "out of host memory"); return nullptr; }
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        orbm_fail(nullptr, ORBM_EHIP, "context set-up failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    return ctx;
+}
+
+void orbm_destroy(orbm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &a : ctx->arenas) if (a.base) (void)hipFree(a.base);
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->d_qsets) (void)hipFree(ctx->d_qsets);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *orbm_last_error(const orbm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int orbm_set_stream(orbm_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ORBM_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ORBM_OK;
+}
+
+int orbm_synchronize(orbm_ctx *ctx) {
+    if (!ctx) return ORBM_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBM_OK;
+}
+
+int orbm_device_info(orbm_ctx *ctx, int32_t *n_cu, int32_t *clock_khz, char *name, int name_len) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = ctx->prop.clockRate;
+    if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    return ORBM_OK;
+}
+
+static int grow_table(orbm_ctx *ctx, void **d_tab, size_t *cap, size_t need, size_t elem) {
+    if (need <= *cap) return ORBM_OK;
+    size_t ncap = *cap ? *cap : 1024;
+    while (ncap < need) ncap *= 2;
+    void *nt = nullptr;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMalloc(&nt, ncap * elem));
+    if (*d_tab) HIPCHK(ctx, hipFree(*d_tab));
+    *d_tab = nt;
+    *cap = ncap;
+    return ORBM_OK;
+}
+
+struct Packer {
+    std::vector<uint8_t> host;
+    size_t off = 0;
+    size_t add(const void *src, size_t bytes) {   // src may be null: reserved, zero-filled
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        host.resize(off, 0);
+        if (src && bytes) memcpy(host.data() + o, src, bytes);
+        return o;
+    }
+};
+
+int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views, int32_t *out_ids) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_frames < 0 || (n_frames > 0 && (!views || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "frames_upload: null argument");
+    if (n_frames == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct Offs { size_t desc, x, y, angle, angle_raw, uright, octave, flags, cell_off, cell_idx, fv_node, fv_off, fv_idx; };
+    std::vector<Offs> offs(n_frames);
+    Packer pk;
+    for (int k = 0; k < n_frames; k++) {
+        const orbm_frame_view &v = views[k];
+        if (v.n < 0 || v.n > 65535) return orbm_fail(ctx, ORBM_ELIMIT, "frame %d: n = %d outside [0, 65535]", k, v.n);
+        if (v.n > 0 && (!v.desc || !v.x || !v.y || !v.angle || !v.octave))
+            return orbm_fail(ctx, ORBM_EINVAL, "frame %d: desc/x/y/angle/octave must be non-null", k);
+        if (v.n_levels < 1 || v.n_levels > ORBM_MAX_LEVELS || !v.scale_factors || !v.level_sigma2)
+            return orbm_fail(ctx, ORBM_EINVAL, "frame %d: n_levels = %d outside [1, %d] or null scale tables", k, v.n_levels, ORBM_MAX_LEVELS);
+        if (v.n_nodes < 0 || (v.n_nodes > 0 && (!v.fv_node || !v.fv_off || !v.fv_idx)))
+            return orbm_fail(ctx, ORBM_EINVAL, "frame %d: bad FeatureVector", k);
+        for (int i = 0; i < v.n; i++)
+            if (v.octave[i] < 0 || v.octave[i] >= v.n_levels)
+                return orbm_fail(ctx, ORBM_EINVAL, "frame %d: octave[%d] = %d outside [0, %d)", k, i, v.octave[i], v.n_levels);
+        uint32_t nfv = v.n_nodes > 0 ? v.fv_off[v.n_nodes] : 0;
+        for (int j = 0; j < v.n_nodes; j++) {
+            if (j > 0 && v.fv_node[j] <= v.fv_node[j - 1]) return orbm_fail(ctx, ORBM_EINVAL, "frame %d: fv_node not strictly ascending", k);
+            if (v.fv_off[j + 1] < v.fv_off[j]) return orbm_fail(ctx, ORBM_EINVAL, "frame %d: fv_off not monotone", k);
+        }
+        for (uint32_t j = 0; j < nfv; j++)
+            if (v.fv_idx[j] >= (uint32_t)v.n) return orbm_fail(ctx, ORBM_EINVAL, "frame %d: fv_idx[%u] out of range", k, j);
+        Offs &o = offs[k];
+        const size_t n = (size_t)v.n;
+        o.desc = pk.add(v.desc, n * 32);
+        o.x = pk.add(v.x, n * 4);
+        o.y = pk.add(v.y, n * 4);
+        o.angle = pk.add(v.angle, n * 4);
+        o.angle_raw = v.angle_raw ? pk.add(v.angle_raw, n * 4) : o.angle;
+        o.uright = pk.add(v.uright, n * 4);
+        if (!v.uright) { float *u = (float *)(pk.host.data() + o.uright); for (size_t i = 0; i < n; i++) u[i] = -1.0f; }
+        o.octave = pk.add(nullptr, n);
+        for (size_t i = 0; i < n; i++) pk.host[o.octave + i] = (uint8_t)v.octave[i];
+        o.flags = pk.add(v.mp_flags, n);
+        o.cell_off = pk.add(nullptr, (ORBM_GRID_CELLS + 1) * 4);
+        o.cell_idx = pk.add(nullptr, (n ? n : 1) * 4);
+        o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4);
+        o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4);
+        o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4);
+    }
+    Arena ar;
+    ar.bytes = pk.off;
+    HIPCHK(ctx, hipMalloc(&ar.base, ar.bytes));
+    hipError_t e = hipMemcpy(ar.base, pk.host.data(), ar.bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(ar.base); return orbm_fail(ctx, ORBM_EHIP, "frame upload copy failed: %s", hipGetErrorString(e)); }
+    ar.live = n_frames;
+    int arena_id = -1;
+    for (size_t i = 0; i < ctx->arenas.size(); i++) if (!ctx->arenas[i].base) { arena_id = (int)i; break; }
+    if (arena_id < 0) { ctx->arenas.push_back(ar); arena_id = (int)ctx->arenas.size() - 1; } else ctx->arenas[arena_id] = ar;
+
+    char *b = (char *)ar.base;
+    size_t lo = SIZE_MAX, hi = 0;
+    for (int k = 0; k < n_frames; k++) {
+        const orbm_frame_view &v = views[k];
+        const Offs &o = offs[k];
+        FrameDev f;
+        memset(&f, 0, sizeof f);
+        f.n = v.n; f.n_nodes = v.n_nodes; f.n_levels = v.n_levels;
+        f.desc = (const uint32_t *)(b + o.desc);
+        f.x = (const float *)(b + o.x); f.y = (const float *)(b + o.y);
+        f.angle = (const float *)(b + o.angle); f.angle_raw = (const float *)(b + o.angle_raw);
+        f.uright = (const float *)(b + o.uright);
+        f.octave = (const uint8_t *)(b + o.octave);
+        f.mp_flags = (uint8_t *)(b + o.flags);
+        f.cell_off = (uint32_t *)(b + o.cell_off); f.cell_idx = (uint32_t *)(b + o.cell_idx);
+        f.fv_node = (const uint32_t *)(b + o.fv_node); f.fv_off = (const uint32_t *)(b + o.fv_off);
+        f.fv_idx = (const uint32_t *)(b + o.fv_idx);
+        f.min_x = v.min_x; f.min_y = v.min_y; f.max_x = v.max_x; f.max_y = v.max_y;
+        f.inv_w = v.inv_w; f.inv_h = v.inv_h;
+        for (int l = 0; l < ORBM_MAX_LEVELS; l++) {
+            f.sf[l] = l < v.n_levels ? v.scale_factors[l] : 0.f;
+            f.sigma2[l] = l < v.n_levels ? v.level_sigma2[l] : 0.f;
+        }
+        int32_t id;
+        if (!ctx->free_frames.empty()) { id = ctx->free_frames.back(); ctx->free_frames.pop_back(); ctx->h_frames[id] = f; ctx->frame_arena[id] = arena_id; }
+        else { id = (int32_t)ctx->h_frames.size(); ctx->h_frames.push_back(f); ctx->frame_arena.push_back(arena_id); }
+        out_ids[k] = id;
+        lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
+    }
+    size_t old_cap = ctx->d_frames_cap;
+    int rc = grow_table(ctx, (void **)&ctx->d_frames, &ctx->d_frames_cap, ctx->h_frames.size(), sizeof(FrameDev));
+    if (rc) return rc;
+    if (ctx->d_frames_cap != old_cap) { lo = 0; hi = ctx->h_frames.size() - 1; }
+    HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, (hi - lo + 1) * sizeof(FrameDev), hipMemcpyHostToDevice));
+    // build the grid-cell CSR on the device
+    rc = orbm_ws_reserve(ctx, (size_t)n_frames * 4);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws, out_ids, (size_t)n_frames * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(build_grid_kernel, dim3(n_frames), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBM_OK;
+}
+
+static void arena_unref(orbm_ctx *ctx, int a) {
+    if (a < 0) return;
+    if (--ctx->arenas[a].live == 0) { (void)hipFree(ctx->arenas[a].base); ctx->arenas[a] = Arena(); }
+}
+
+int orbm_frames_free(orbm_ctx *ctx, int n_frames, const int32_t *ids) {
+    if (!ctx) return ORBM_EINVAL;
+    int rc = orbm_check_frames(ctx, n_frames, ids, "ids");
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_frames; i++) {
+        int32_t id = ids[i];
+        if (ctx->frame_arena[id] < 0) continue;  // duplicate in the list
+        arena_unref(ctx, ctx->frame_arena[id]);
+        ctx->frame_arena[id] = -1;
+        ctx->free_frames.push_back(id);
+    }
+    return ORBM_OK;
+}
+
+int orbm_frame_set_mp_flags(orbm_ctx *ctx, int32_t id, const uint8_t *mp_flags) {
+    if (!ctx) return ORBM_EINVAL;
+    int rc = orbm_check_frames(ctx, 1, &id, "id");
+    if (rc) return rc;
+    if (!mp_flags) return orbm_fail(ctx, ORBM_EINVAL, "mp_flags is null");
+    const FrameDev &f = ctx->h_frames[id];
+    HIPCHK(ctx, hipMemcpyAsync(f.mp_flags, mp_flags, (size_t)f.n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBM_OK;
+}
+
+int orbm_frame_grid_download(orbm_ctx *ctx, int32_t id, uint32_t *cell_off, uint32_t *cell_idx) {
+    if (!ctx) return ORBM_EINVAL;
+    int rc = orbm_check_frames(ctx, 1, &id, "id");
+    if (rc) return rc;
+    const FrameDev &f = ctx->h_frames[id];
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (cell_off) HIPCHK(ctx, hipMemcpy(cell_off, f.cell_off, (ORBM_GRID_CELLS + 1) * 4, hipMemcpyDeviceToHost));
+    if (cell_idx && f.n > 0) HIPCHK(ctx, hipMemcpy(cell_idx, f.cell_idx, (size_t)f.n * 4, hipMemcpyDeviceToHost));
+    return ORBM_OK;
+}
+
+static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, const orbm_win_queries *wsets, int32_t *out_ids) {
+    if (n_sets < 0 || (n_sets > 0 && ((!ps && !wsets) || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "queries_upload: null argument");
+    if (n_sets == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct Offs { size_t desc, f0, f1, f2, f3, angle, l0, l1, flags; bool has_f3, has_angle; };
+    std::vector<Offs> offs(n_sets);
+    Packer pk;
+    for (int k = 0; k < n_sets; k++) {
+        Offs &o = offs[k];
+        if (ps) {
+            const orbm_proj_queries &q = ps[k];
+            if (q.n < 0) return orbm_fail(ctx, ORBM_EINVAL, "query set %d: n < 0", k);
+            if (q.n > 0 && (!q.desc || !q.proj_x || !q.proj_y || !q.proj_xr || !q.level || !q.view_cos))
+                return orbm_fail(ctx, ORBM_EINVAL, "query set %d: null array", k);
+            const size_t n = (size_t)q.n;
+            for (size_t i = 0; i < n; i++)
+                if (q.level[i] < 0 || q.level[i] >= ORBM_MAX_LEVELS) return orbm_fail(ctx, ORBM_EINVAL, "query set %d: level[%zu] out of range", k, i);
+            o.desc = pk.add(q.desc, n * 32);
+            o.f0 = pk.add(q.proj_x, n * 4); o.f1 = pk.add(q.proj_y, n * 4); o.f2 = pk.add(q.proj_xr, n * 4);
+            o.f3 = pk.add(q.view_cos, n * 4); o.has_f3 = true; o.has_angle = false; o.angle = 0;
+            o.l0 = pk.add(q.level, n * 4); o.l1 = o.l0;
+            o.flags = pk.add(q.flags, n);
+            if (!q.flags) memset(pk.host.data() + o.flags, ORBM_Q_VALID | ORBM_Q_OBS, n);
+        } else {
+            const orbm_win_queries &q = wsets[k];
+            if (q.n < 0) return orbm_fail(ctx, ORBM_EINVAL, "query set %d: n < 0", k);
+            if (q.n > 0 && (!q.desc || !q.u || !q.v || !q.radius || !q.min_level || !q.max_level))
+                return orbm_fail(ctx, ORBM_EINVAL, "query set %d: null array", k);
+            const size_t n = (size_t)q.n;
+            o.desc = pk.add(q.desc, n * 32);
+            o.f0 = pk.add(q.u, n * 4); o.f1 = pk.add(q.v, n * 4); o.f2 = pk.add(q.radius, n * 4);
+            o.has_f3 = q.ur != nullptr; o.f3 = o.has_f3 ? pk.add(q.ur, n * 4) : 0;
+            o.has_angle = q.angle != nullptr; o.angle = o.has_angle ? pk.add(q.angle, n * 4) : 0;
+            o.l0 = pk.add(q.min_level, n * 4); o.l1 = pk.add(q.max_level, n * 4);
+            o.flags = pk.add(q.flags, n);
+            if (!q.flags) memset(pk.host.data() + o.flags, ORBM_Q_VALID | ORBM_Q_OBS, n);
+        }
+    }
+    Arena ar;
+    ar.bytes = pk.off ? pk.off : 256;
+    HIPCHK(ctx, hipMalloc(&ar.base, ar.bytes));
+    if (pk.off) {
+        hipError_t e = hipMemcpy(ar.base, pk.host.data(), pk.off, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(ar.base); return orbm_fail(ctx, ORBM_EHIP, "query upload copy failed: %s", hipGetErrorString(e)); }
+    }
+    ar.live = n_sets;
+    int arena_id = -1;
+    for (size_t i = 0; i < ctx->arenas.size(); i++) if (!ctx->arenas[i].base) { arena_id = (int)i; break; }
+    if (arena_id < 0) { ctx->arenas.push_back(ar); arena_id = (int)ctx->arenas.size() - 1; } else ctx->arenas[arena_id] = ar;
+    char *b = (char *)ar.base;
+    size_t lo = SIZE_MAX, hi = 0;
+    for (int k = 0; k < n_sets; k++) {
+        const Offs &o = offs[k];
+        QSetDev q;
+        memset(&q, 0, sizeof q);
+        q.n = ps ? ps[k].n : wsets[k].n;
+        q.kind = ps ? 0 : 1;
+        q.desc = (const uint32_t *)(b + o.desc);
+        q.f0 = (const float *)(b + o.f0); q.f1 = (const float *)(b + o.f1); q.f2 = (const float *)(b + o.f2);
+        q.f3 = o.has_f3 ? (const float *)(b + o.f3) : nullptr;
+        q.angle = o.has_angle ? (const float *)(b + o.angle) : nullptr;
+        q.l0 = (const int32_t *)(b + o.l0); q.l1 = (const int32_t *)(b + o.l1);
+        q.flags = (const uint8_t *)(b + o.flags);
+        int32_t id;
+        if (!ctx->free_qsets.empty()) { id = ctx->free_qsets.back(); ctx->free_qsets.pop_back(); ctx->h_qsets[id] = q; ctx->qset_arena[id] = arena_id; }
+        else { id = (int32_t)ctx->h_qsets.size(); ctx->h_qsets.push_back(q); ctx->qset_arena.push_back(arena_id); }
+        out_ids[k] = id;
+        lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
+    }
+    size_t old_cap = ctx->d_qsets_cap;
+    int rc = grow_table(ctx, (void **)&ctx->d_qsets, &ctx->d_qsets_cap, ctx->h_qsets.size(), sizeof(QSetDev));
+    if (rc) return rc;
+    if (ctx->d_qsets_cap != old_cap) { lo = 0; hi = ctx->h_qsets.size() - 1; }
+    HIPCHK(ctx, hipMemcpy(ctx->d_qsets + lo, ctx->h_qsets.data() + lo, (hi - lo + 1) * sizeof(QSetDev), hipMemcpyHostToDevice));
+    return ORBM_OK;
+}
+
+int orbm_proj_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *sets, int32_t *out_ids) {
+    if (!ctx) return ORBM_EINVAL;
+    return upload_qsets(ctx, n_sets, sets, nullptr, out_ids);
+}
+
+int orbm_win_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_win_queries *sets, int32_t *out_ids) {
+    if (!ctx) return ORBM_EINVAL;
+    return upload_qsets(ctx, n_sets, nullptr, sets, out_ids);
+}
+
+int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids) {
+    if (!ctx) return ORBM_EINVAL;
+    for (int i = 0; i < n_sets; i++) {
+        int32_t id = ids[i];
+        if (id < 0 || (size_t)id >= ctx->h_qsets.size()) return orbm_fail(ctx, ORBM_EINVAL, "ids[%d] = %d out of range", i, id);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_sets; i++) {
+        int32_t id = ids[i];
+        if (ctx->qset_arena[id] < 0) continue;
+        arena_unref(ctx, ctx->qset_arena[id]);
+        ctx->qset_arena[id] = -1;
+        ctx->free_qsets.push_back(id);
+    }
+    return ORBM_OK;
+}
+
+int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist, int io_on_device) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n < 0 || (n > 0 && (!a || !b || !dist))) return orbm_fail(ctx, ORBM_EINVAL, "hamming256_pairs: null argument");
+    if (n == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (io_on_device && ((((uintptr_t)a) | ((uintptr_t)b)) & 15))
+        return orbm_fail(ctx, ORBM_EINVAL, "hamming256_pairs: device rows must be 16-byte aligned");
+    IoStage io(ctx, io_on_device);
+    if (!io_on_device) { int rc = orbm_ws_reserve(ctx, (size_t)n * 68 + 1024); if (rc) return rc; }
+    const void *da, *db; void *dd;
+    int rc;
+    if ((rc = io.in(a, (size_t)n * 32, &da)) || (rc = io.in(b, (size_t)n * 32, &db)) || (rc = io.out(dist, (size_t)n * 4, &dd))) return rc;
+    hipLaunchKernelGGL(hamming_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const uint4 *)da, (const uint4 *)db, (int32_t *)dd);
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
+}
+
+int orbm_popcount_peak(orbm_ctx *ctx, int iters, double *lane_ops_per_s) {
+    if (!ctx || !lane_ops_per_s || iters <= 0) return ORBM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int blocks = ctx->prop.multiProcessorCount * 8;  // 8 x 256 threads = 32 waves per CU
+    int rc = orbm_ws2_reserve(ctx, (size_t)blocks * 256 * 4);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(popcount_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters / 8 + 1, 12345u, (uint32_t *)ctx->ws2);  // warm-up
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(popcount_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters, 777u, (uint32_t *)ctx->ws2);
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // per iteration and lane: 4 x 8 x (xor + bcnt) = 64 lane-ops (the scalar LCG is not counted)
+    *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * 64.0 / ((double)ms * 1e-3);
+    return ORBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// orbm_internal.h -- shared declarations of liborbmatch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/orbmatch.h"
+
+// Device-resident layout of one Frame / KeyFrame (replaces Frame.h:235-291 / KeyFrame.h:232-282):
+//  desc      packed 32-byte rows, 256-byte aligned base, row i = keypoint i
+//  x,y,...   keypoint SoA
+//  cell_*    64x48 grid as CSR, cell = ix*48+iy, indices ascending inside a cell (Frame.cc:278-298)
+//  fv_*      DBoW2::FeatureVector as CSR (nodes ascending)
+struct FrameDev {
+    int32_t n, n_nodes, n_levels, pad0;
+    const uint32_t *desc;
+    const float *x, *y, *angle, *angle_raw, *uright;
+    const uint8_t *octave;
+    uint8_t *mp_flags;
+    uint32_t *cell_off, *cell_idx;
+    const uint32_t *fv_node, *fv_off, *fv_idx;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+    float sf[ORBM_MAX_LEVELS];
+    float sigma2[ORBM_MAX_LEVELS];
+};
+
+// Device-resident query set: orbm_proj_queries (kind 0) or orbm_win_queries (kind 1).
+struct QSetDev {
+    int32_t n, kind;
+    const uint32_t *desc;
+    const float *f0, *f1, *f2, *f3;   // kind0: proj_x, proj_y, proj_xr, view_cos | kind1: u, v, radius, ur(null ok)
+    const float *angle;               // kind1 only, may be null
+    const int32_t *l0, *l1;           // kind0: level, - | kind1: min_level, max_level
+    const uint8_t *flags;
+};
+
+struct Arena {
+    void *base = nullptr;
+    size_t bytes = 0;
+    int live = 0;  // objects still referencing it
+};
+
+struct orbm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+    // frame table
+    std::vector<FrameDev> h_frames;
+    std::vector<int> frame_arena;      // arena index per slot, -1 = free slot
+    std::vector<int32_t> free_frames;
+    FrameDev *d_frames = nullptr;
+    size_t d_frames_cap = 0;
+    // query-set table
+    std::vector<QSetDev> h_qsets;
+    std::vector<int> qset_arena;
+    std::vector<int32_t> free_qsets;
+    QSetDev *d_qsets = nullptr;
+    size_t d_qsets_cap = 0;
+    std::vector<Arena> arenas;
+    // grow-only workspace for staged host I/O and kernel scratch
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    void *ws2 = nullptr;   // kernel scratch (separate from I/O staging)
+    size_t ws2_bytes = 0;
+};
+
+int orbm_fail(orbm_ctx *ctx, int code, const char *fmt, ...);
+#define HIPCHK(ctx, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return orbm_fail(ctx, ORBM_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
+int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
+int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
+int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
+
+// Helper that stages host index lists / outputs through the I/O workspace when io_on_device == 0.
+struct IoStage {
+    orbm_ctx *ctx;
+    bool dev;
+    size_t used = 0;
+    struct Out { void *host; void *devp; size_t bytes; };
+    std::vector<Out> outs;
+    IoStage(orbm_ctx *c, int io_on_device) : ctx(c), dev(io_on_device != 0) {}
+    // total bytes must have been reserved with orbm_ws_reserve before the first in()/out()
+    void *carve(size_t bytes);
+    int in(const void *p, size_t bytes, const void **devp);          // copies host->device if needed
+    int out(void *p, size_t bytes, void **devp);                     // registers device->host copy
+    int finish();                                                    // copies outputs back + sync (host mode)
+};
+
+// ---- device helpers (gfx950) -------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// 256-bit Hamming distance: 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate)  [ORBmatcher.cc:2184-2200]
+__device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    // the accumulate chain is written as asm: left to itself hipcc re-associates the eight adds into
+    // 8 x v_bcnt(x, 0) + 3 x v_add3_u32, i.e. 19 instead of 16 VALU ops per comparison.
+    uint32_t d = __builtin_popcount(a[0] ^ b[0]);
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        const uint32_t x = a[i] ^ b[i];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    return d;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): remap so that consecutive logical ids
+// share an L2.  Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t orig, uint32_t nwg) {
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// rotation-histogram bin, ORBmatcher.cc:323-328
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+    const float factor = 1.0f / ORBM_HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ComputeThreeMaxima, ORBmatcher.cc:2135-2178 (single lane)
+__device__ __forceinline__ void three_maxima(const int *sizes, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+        const int s = sizes[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s; ind3 = i;
+        }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+        ind2 = -1; ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+        ind3 = -1;
+    }
+}
+#endif

@@ -1,0 +1,220 @@
+"""Python host layer over the C ABI (include/orbmatch.h): one `Context` per calling thread / GPU.
+
+Methods mirror the ORB_SLAM2::ORBmatcher searches in their flat, batched form.  The numpy forms
+stage index lists and outputs through the library (io_on_device = 0); the `*_dev` forms take raw
+device addresses (e.g. torch tensors' data_ptr()) and only enqueue work on the context's stream.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .views import CFrameView, CProjQueries, CWinQueries, FrameData, ProjQueries, WinQueries, GRID_CELLS
+
+
+class OrbmError(RuntimeError):
+    pass
+
+
+def _addr(a) -> Optional[int]:
+    """host numpy array -> address (keeps no reference; caller holds the array)"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._h = self._L.orbm_create(device)
+        if not self._h:
+            raise OrbmError("orbm_create failed: " + self._L.orbm_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int) -> int:
+        if rc < 0:
+            raise OrbmError(f"orbm error {rc}: " + self._L.orbm_last_error(self._h).decode())
+        return rc
+
+    # ---- context ----
+    def set_stream(self, hip_stream: Optional[int]):
+        self._chk(self._L.orbm_set_stream(self._h, hip_stream))
+
+    def synchronize(self):
+        self._chk(self._L.orbm_synchronize(self._h))
+
+    def device_info(self):
+        ncu, clk = C.c_int32(0), C.c_int32(0)
+        name = C.create_string_buffer(256)
+        self._chk(self._L.orbm_device_info(self._h, C.byref(ncu), C.byref(clk), name, 256))
+        return {"n_cu": ncu.value, "clock_khz": clk.value, "name": name.value.decode()}
+
+    def popcount_peak(self, iters: int = 4096) -> float:
+        r = C.c_double(0)
+        self._chk(self._L.orbm_popcount_peak(self._h, iters, C.byref(r)))
+        return r.value
+
+    # ---- storage ----
+    def upload_frames(self, frames: Sequence[FrameData]) -> np.ndarray:
+        n = len(frames)
+        arr = (CFrameView * max(n, 1))()
+        keep = []
+        for i, f in enumerate(frames):
+            v = f.view()
+            keep.append(v)
+            arr[i] = v
+        ids = np.zeros(max(n, 1), np.int32)
+        self._chk(self._L.orbm_frames_upload(self._h, n, arr, _addr(ids)))
+        return ids[:n]
+
+    def free_frames(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._chk(self._L.orbm_frames_free(self._h, len(ids), _addr(ids)))
+
+    def set_mp_flags(self, fid: int, flags: np.ndarray):
+        flags = np.ascontiguousarray(flags, np.uint8)
+        self._chk(self._L.orbm_frame_set_mp_flags(self._h, int(fid), _addr(flags)))
+
+    def grid(self, fid: int, n: int):
+        off = np.zeros(GRID_CELLS + 1, np.uint32)
+        idx = np.zeros(max(n, 1), np.uint32)
+        self._chk(self._L.orbm_frame_grid_download(self._h, int(fid), _addr(off), _addr(idx)))
+        return off, idx[: int(off[-1])]
+
+    def upload_proj_queries(self, sets: Sequence[ProjQueries]) -> np.ndarray:
+        n = len(sets)
+        arr = (CProjQueries * max(n, 1))()
+        keep = [s.view() for s in sets]
+        for i, v in enumerate(keep):
+            arr[i] = v
+        ids = np.zeros(max(n, 1), np.int32)
+        self._chk(self._L.orbm_proj_queries_upload(self._h, n, arr, _addr(ids)))
+        return ids[:n]
+
+    def upload_win_queries(self, sets: Sequence[WinQueries]) -> np.ndarray:
+        n = len(sets)
+        arr = (CWinQueries * max(n, 1))()
+        keep = [s.view() for s in sets]
+        for i, v in enumerate(keep):
+            arr[i] = v
+        ids = np.zeros(max(n, 1), np.int32)
+        self._chk(self._L.orbm_win_queries_upload(self._h, n, arr, _addr(ids)))
+        return ids[:n]
+
+    def free_queries(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._chk(self._L.orbm_queries_free(self._h, len(ids), _addr(ids)))
+
+    # ---- a1 ----
+    def hamming_pairs(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        assert a.shape == b.shape
+        out = np.zeros(max(a.shape[0], 1), np.int32)
+        self._chk(self._L.orbm_hamming256_pairs(self._h, a.shape[0], _addr(a), _addr(b), _addr(out), 0))
+        return out[: a.shape[0]]
+
+    # ---- config 2 ----
+    def bf2nn(self, fa, fb, ratio: float, th: int, stride: int, want_dist: bool = True):
+        fa = np.ascontiguousarray(fa, np.int32)
+        fb = np.ascontiguousarray(fb, np.int32)
+        p = len(fa)
+        match = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        bd = np.full_like(match, 256) if want_dist else None
+        sd = np.full_like(match, 256) if want_dist else None
+        counts = np.zeros(max(p, 1), np.int32)
+        self._chk(self._L.orbm_bf2nn_batch(self._h, p, _addr(fa), _addr(fb), ratio, th, stride, _addr(match),
+                                           _addr(bd), _addr(sd), _addr(counts), 0))
+        return counts[:p], match[:p], (bd[:p] if want_dist else None), (sd[:p] if want_dist else None)
+
+    def bf2nn_dev(self, n_pairs, fa_ptr, fb_ptr, ratio, th, stride, match_ptr, best_ptr, second_ptr, counts_ptr):
+        self._chk(self._L.orbm_bf2nn_batch(self._h, n_pairs, fa_ptr, fb_ptr, ratio, th, stride, match_ptr, best_ptr,
+                                           second_ptr, counts_ptr, 1))
+
+    # ---- a7 / a8 ----
+    def search_bow(self, variant: int, fa, fb, ratio: float, check_ori: bool, stride: int):
+        fa = np.ascontiguousarray(fa, np.int32)
+        fb = np.ascontiguousarray(fb, np.int32)
+        p = len(fa)
+        match = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        counts = np.zeros(max(p, 1), np.int32)
+        self._chk(self._L.orbm_search_bow_batch(self._h, variant, p, _addr(fa), _addr(fb), ratio, int(check_ori),
+                                                stride, _addr(match), _addr(counts), 0))
+        return counts[:p], match[:p]
+
+    def search_bow_dev(self, variant, n_pairs, fa_ptr, fb_ptr, ratio, check_ori, stride, match_ptr, counts_ptr):
+        self._chk(self._L.orbm_search_bow_batch(self._h, variant, n_pairs, fa_ptr, fb_ptr, ratio, int(check_ori),
+                                                stride, match_ptr, counts_ptr, 1))
+
+    # ---- a9 ----
+    def search_triang(self, fa, fb, f12, epipole, only_stereo: bool, check_ori: bool, stride: int):
+        fa = np.ascontiguousarray(fa, np.int32)
+        fb = np.ascontiguousarray(fb, np.int32)
+        p = len(fa)
+        f12 = np.ascontiguousarray(f12, np.float32).reshape(p, 9)
+        ep = np.ascontiguousarray(epipole, np.float32).reshape(p, 2)
+        match = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        counts = np.zeros(max(p, 1), np.int32)
+        self._chk(self._L.orbm_search_triang_batch(self._h, p, _addr(fa), _addr(fb), _addr(f12), _addr(ep),
+                                                   int(only_stereo), int(check_ori), stride, _addr(match),
+                                                   _addr(counts), 0))
+        return counts[:p], match[:p]
+
+    # ---- a6 ----
+    def search_proj_points(self, frames, qsets, th: float, ratio: float, stride: int, slot_flags=None):
+        fr = np.ascontiguousarray(frames, np.int32)
+        qs = np.ascontiguousarray(qsets, np.int32)
+        k = len(fr)
+        owner = np.full((max(k, 1), max(stride, 1)), -1, np.int32)
+        counts = np.zeros(max(k, 1), np.int32)
+        sf = None
+        if slot_flags is not None:
+            sf = np.ascontiguousarray(slot_flags, np.uint8)
+            assert sf.shape == (k, stride)
+        self._chk(self._L.orbm_search_proj_points_batch(self._h, k, _addr(fr), _addr(qs), th, ratio, _addr(sf),
+                                                        stride, _addr(owner), _addr(counts), 0))
+        return counts[:k], owner[:k]
+
+    def search_proj_points_dev(self, n_inst, frame_ptr, qset_ptr, th, ratio, slot_flags_ptr, stride, owner_ptr,
+                               counts_ptr):
+        self._chk(self._L.orbm_search_proj_points_batch(self._h, n_inst, frame_ptr, qset_ptr, th, ratio,
+                                                        slot_flags_ptr, stride, owner_ptr, counts_ptr, 1))
+
+    # ---- a11 ----
+    def search_window(self, mode: int, frames, qsets, dist_th: int, check_ori: bool, stride: int, slot_flags=None):
+        fr = np.ascontiguousarray(frames, np.int32)
+        qs = np.ascontiguousarray(qsets, np.int32)
+        k = len(fr)
+        owner = np.full((max(k, 1), max(stride, 1)), -1, np.int32)
+        counts = np.zeros(max(k, 1), np.int32)
+        sf = None
+        if slot_flags is not None:
+            sf = np.ascontiguousarray(slot_flags, np.uint8)
+            assert sf.shape == (k, stride)
+        self._chk(self._L.orbm_search_window_batch(self._h, mode, k, _addr(fr), _addr(qs), dist_th, int(check_ori),
+                                                   _addr(sf), stride, _addr(owner), _addr(counts), 0))
+        return counts[:k], owner[:k]
+
+    # ---- a5 ----
+    def search_init(self, f1: int, f2: int, prev_xy: np.ndarray, window: int, ratio: float, check_ori: bool):
+        prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+        n1 = prev.shape[0]
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        cnt = self._chk(self._L.orbm_search_init(self._h, int(f1), int(f2), _addr(prev), window, ratio,
+                                                 int(check_ori), _addr(m12)))
+        return cnt, m12[:n1], prev

@@ -1,0 +1,101 @@
+"""GPU parity: a1 (DescriptorDistance), a15 (grid build) and BASELINE config 2 (brute-force 2-NN) through
+the C ABI against the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from orbslam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hamming_pairs_matches_swar(ctx, orc):
+    rng = np.random.default_rng(1)
+    a = synth.random_descriptors(rng, 5000)
+    b = synth.random_descriptors(rng, 5000)
+    b[:10] = a[:10]                      # distance 0
+    b[10:20] = ~a[10:20]                 # distance 256
+    got = ctx.hamming_pairs(a, b)
+    want = np.array([orc.hamming256(a[i], b[i]) for i in range(len(a))], np.int32)
+    assert np.array_equal(got, want)
+    assert got[:10].max() == 0 and got[10:20].min() == 256
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 2000])
+def test_grid_build_matches_oracle(ctx, orc, n):
+    rng = np.random.default_rng(100 + n)
+    lm = synth.random_descriptors(rng, max(n, 1))
+    # include keypoints outside the image bounds and exactly on cell borders
+    x = rng.uniform(-20, 660, n).astype(np.float32)
+    y = rng.uniform(-20, 500, n).astype(np.float32)
+    if n >= 63:
+        x[:20] = np.arange(20, dtype=np.float32) * 5.0   # multiples of half a cell: round() ties
+        y[:20] = 15.0
+    f = synth.make_frame(rng, lm, np.arange(n), x=x, y=y, with_fv=False)
+    ids = ctx.upload_frames([f])
+    off, idx = ctx.grid(ids[0], n)
+    woff, widx = orc.build_grid(f)
+    assert np.array_equal(off, woff)
+    assert np.array_equal(idx, widx)
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("na,nb", [(2000, 2000), (1, 1), (513, 77), (64, 1025), (700, 0), (0, 300)])
+def test_bf2nn_parity(ctx, orc, na, nb):
+    rng = np.random.default_rng(na * 7 + nb)
+    n = max(na, nb, 1)
+    a, b = synth.bf_pair(seed=na * 31 + nb, n=n)
+    fa = synth.make_frame(rng, a.desc, np.arange(na), with_fv=False, p_flip=0.0)
+    fb = synth.make_frame(rng, b.desc, np.arange(nb), with_fv=False, p_flip=0.0)
+    ids = ctx.upload_frames([fa, fb])
+    counts, match, bd, sd = ctx.bf2nn([ids[0]], [ids[1]], 0.75, 50, stride=max(na, 1))
+    wc, wm, wbd, wsd, ncmp = orc.bf2nn(fa, fb, 0.75, 50)
+    assert ncmp == na * nb
+    assert counts[0] == wc
+    assert np.array_equal(match[0, :na], wm)
+    assert np.array_equal(bd[0, :na], wbd)
+    assert np.array_equal(sd[0, :na], wsd)
+    ctx.free_frames(ids)
+
+
+def test_bf2nn_ties_first_wins_and_duplicates(ctx, orc):
+    """Equal distances: the lower candidate index wins and the duplicate counts as second best, so the ratio
+    test (ratio < 1) rejects the row (SURVEY 8c known answers)."""
+    rng = np.random.default_rng(5)
+    q = synth.random_descriptors(rng, 128)
+    c = synth.random_descriptors(rng, 300)
+    c[7] = q[3]; c[200] = q[3]            # two exact duplicates of query 3
+    c[50] = q[9]; c[50, 0] ^= 1           # distance 1
+    c[60] = q[9]; c[60, 5] ^= 16          # distance 1 again, later index
+    c[100] = ~q[11]                       # distance 256 must never become "best"
+    fa = synth.make_frame(rng, q, np.arange(128), with_fv=False, p_flip=0.0)
+    fb = synth.make_frame(rng, c, np.arange(300), with_fv=False, p_flip=0.0)
+    ids = ctx.upload_frames([fa, fb])
+    counts, match, bd, sd = ctx.bf2nn([ids[0]], [ids[1]], 0.9, 50, stride=128)
+    wc, wm, wbd, wsd, _ = orc.bf2nn(fa, fb, 0.9, 50)
+    assert np.array_equal(match[0], wm) and np.array_equal(bd[0], wbd) and np.array_equal(sd[0], wsd)
+    assert bd[0, 3] == 0 and sd[0, 3] == 0 and match[0, 3] == -1
+    assert bd[0, 9] == 1 and sd[0, 9] == 1 and match[0, 9] == -1
+    # with ratio > 1 the tie is accepted and the FIRST index must be reported
+    counts, match, _, _ = ctx.bf2nn([ids[0]], [ids[1]], 1.5, 50, stride=128)
+    _, wm, _, _, _ = orc.bf2nn(fa, fb, 1.5, 50)
+    assert np.array_equal(match[0], wm)
+    assert match[0, 3] == -1 and match[0, 9] == 50   # 0 < 1.5*0 is false; 1 < 1.5*1 holds
+    ctx.free_frames(ids)
+
+
+def test_bf2nn_batch_many_pairs(ctx, orc):
+    kfs = synth.keyframe_pool(seed=77, n_kf=6, n=500, window=900)
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.triu_indices(6, 1)
+    counts, match, bd, sd = ctx.bf2nn(ids[pa], ids[pb], 0.75, 50, stride=500)
+    for k, (i, j) in enumerate(zip(pa, pb)):
+        wc, wm, wbd, wsd, _ = orc.bf2nn(kfs[i], kfs[j], 0.75, 50)
+        assert counts[k] == wc, (i, j)
+        assert np.array_equal(match[k], wm) and np.array_equal(bd[k], wbd) and np.array_equal(sd[k], wsd)
+    ctx.free_frames(ids)
+
+
+def test_errors_are_loud(ctx):
+    from orbslam2_amd.matcher import OrbmError
+    with pytest.raises(OrbmError):
+        ctx.bf2nn([12345], [0], 0.75, 50, stride=10)
