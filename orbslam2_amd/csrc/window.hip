@@ -1,13 +1,432 @@
-// window.hip -- grid-cell windowed matching (a5, a6, a11).  PLACEHOLDER: replaced by the real kernels next.
+// window.hip -- grid-cell windowed matching with in-order claims:
+//   a6  SearchByProjection(Frame&, vector<MapPoint*>&, th)             ORBmatcher.cc:57-166     (MODE_PROJ)
+//   a11 SearchByProjection(Cur, Last, th, mono)                        ORBmatcher.cc:1768-1950  (MODE_LAST)
+//       SearchByProjection(Cur, KF, sAlreadyFound, th, ORBdist)        ORBmatcher.cc:1963-2123  (MODE_KF)
+//       SearchByProjection(KF, Scw, vpPoints, vpMatched, th)           ORBmatcher.cc:401-542    (MODE_SIM3)
+//   a5  SearchForInitialization                                       ORBmatcher.cc:562-689    (MODE_INIT)
+// on top of Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea (a13, a14: Frame.cc:434-498,
+// KeyFrame.cc:766-812) walked on the device-resident grid CSR.
+//
+// The reference processes queries one after the other and a query's accepted match changes what later
+// queries may see (F.mvpMapPoints[idx], vpMatched[idx], vMatchedDistance[idx]).  To run queries in
+// parallel and still return exactly the sequential result, one workgroup owns one (frame, query set)
+// instance, keeps the per-keypoint slot state in LDS and takes the queries in index order, one chunk of
+// blockDim queries at a time (one query per lane, its descriptor and window in registers, read from HBM
+// once).  Inside a chunk it iterates rounds:
+//   evaluate : every unresolved query walks its window in reference order against the current slot state
+//              and posts its chunk-local index with atomicMin on every slot it could still claim
+//              (distance <= acceptance threshold);
+//   decide   : a query is FINAL iff no lower-index unresolved query posted on any slot of its window;
+//              final queries apply their result to the slot state.
+// A query can only ever claim a slot it posted on, so a final query has seen the exact state the
+// sequential loop would have shown it; the lowest unresolved query is always final, so every round
+// makes progress.  Typical inputs need 2-4 rounds per chunk.
+#include <limits.h>
+#include <string.h>
+#include <algorithm>
 #include "orbm_internal.h"
-extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int, const int32_t *, const int32_t *, float, float,
-                                             const uint8_t *, int32_t, int32_t *, int32_t *, int) {
-    return orbm_fail(ctx, ORBM_EINVAL, "search_proj_points_batch: not built yet");
+
+namespace {
+
+enum { MODE_LAST = 0, MODE_KF = 1, MODE_SIM3 = 2, MODE_INIT = 3, MODE_PROJ = 10 };
+
+constexpr int WIN_MAX_N = 8192;       // slot state lives in LDS: 5 x 4 B per keypoint
+constexpr uint32_t NOPOST = 0xFFFFFFFFu;
+
+struct WinParams {
+    const FrameDev *frames;
+    const QSetDev *qsets;
+    const int32_t *frame_ids;
+    const int32_t *qset_ids;     // MODE_INIT: id of frame 1 (the query frame)
+    const uint8_t *slot_flags;   // nullable, n_inst x stride
+    float *prev_xy;              // MODE_INIT only
+    int32_t *out;                // owner (n_inst x stride) | MODE_INIT: matches12
+    int32_t *counts;
+    float th, ratio;
+    int dist_th, check_ori, stride, window;
+};
+
+// Frame::GetFeaturesInArea (Frame.cc:434-498) / KeyFrame::GetFeaturesInArea (KeyFrame.cc:766-812):
+// calls body(k, octave) for every keypoint the reference would push, in the reference's order.
+template <bool KF_MODE, typename Body>
+__device__ __forceinline__ void walk_window(const FrameDev &f, float x, float y, float r, int minLevel, int maxLevel,
+                                            Body &&body) {
+    const float xr = __fsub_rn(x, f.min_x), yr = __fsub_rn(y, f.min_y);
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), f.inv_w)));
+    if (nMinCellX >= ORBM_GRID_COLS) return;
+    const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), f.inv_w)));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), f.inv_h)));
+    if (nMinCellY >= ORBM_GRID_ROWS) return;
+    const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), f.inv_h)));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = !KF_MODE && ((minLevel > 0) || (maxLevel >= 0));
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        // cells (ix, nMinCellY..nMaxCellY) are consecutive in the CSR: one contiguous index range
+        const uint32_t b = f.cell_off[ix * ORBM_GRID_ROWS + nMinCellY];
+        const uint32_t e = f.cell_off[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
+        for (uint32_t j = b; j < e; j++) {
+            const int k = (int)f.cell_idx[j];
+            const int oct = f.octave[k];
+            if (bCheckLevels) {
+                if (oct < minLevel) continue;
+                if (maxLevel >= 0 && oct > maxLevel) continue;
+            }
+            const float distx = __fsub_rn(f.x[k], x), disty = __fsub_rn(f.y[k], y);
+            if (fabsf(distx) < r && fabsf(disty) < r) body(k, oct);
+        }
+    }
 }
-extern "C" int orbm_search_window_batch(orbm_ctx *ctx, int, int, const int32_t *, const int32_t *, int, int,
-                                        const uint8_t *, int32_t, int32_t *, int32_t *, int) {
-    return orbm_fail(ctx, ORBM_EINVAL, "search_window_batch: not built yet");
+
+template <int MODE>
+__global__ void window_kernel(WinParams P) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int inst = blockIdx.x;
+    const FrameDev &F = P.frames[P.frame_ids[inst]];
+    const int n = F.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    // LDS carve: state[n] (flags | vMatchedDistance), owner[n], post[2][n], binmask[n], hist[30], misc
+    uint32_t *state = lds;
+    int32_t *owner = (int32_t *)(lds + n);
+    uint32_t *post0 = lds + 2 * (size_t)n, *post1 = lds + 3 * (size_t)n;
+    uint32_t *binmask = lds + 4 * (size_t)n;
+    int *hist = (int *)(lds + 5 * (size_t)n);
+    int *nmatch = hist + 32;
+    int *keep = hist + 33;
+
+    // query source
+    const QSetDev *QS = nullptr;
+    const FrameDev *F1 = nullptr;
+    int Q;
+    if (MODE == MODE_INIT) { F1 = &P.frames[P.qset_ids[inst]]; Q = F1->n; }
+    else { QS = &P.qsets[P.qset_ids[inst]]; Q = QS->n; }
+    int32_t *out = P.out + (size_t)inst * P.stride;
+
+    for (int i = tid; i < n; i += nthr) {
+        uint32_t s0;
+        if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
+        else s0 = P.slot_flags ? P.slot_flags[(size_t)inst * P.stride + i] : F.mp_flags[i];
+        state[i] = s0;
+        owner[i] = -1;
+        post0[i] = NOPOST; post1[i] = NOPOST;
+        binmask[i] = 0;
+    }
+    if (MODE == MODE_INIT) for (int i = tid; i < Q; i += nthr) out[i] = -1;              // vnMatches12 (:566)
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) *nmatch = 0;
+    __syncthreads();
+
+    const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
+                          (MODE == MODE_INIT || QS->angle != nullptr);
+    const bool bFactor = P.th != 1.0f;                                                     // :61
+    int my_matches = 0;
+
+    for (int base = 0; base < Q; base += nthr) {
+        const int qi = base + tid;
+        // ---- load this lane's query (HBM is read once per query) --------------------------------------
+        bool unresolved = false;
+        uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float x = 0, y = 0, r = 0, xr = 0, qangle = 0;
+        int minL = -1, maxL = -1;
+        uint32_t qflags = 0;
+        if (qi < Q) {
+            if (MODE == MODE_INIT) {
+                if (F1->octave[qi] == 0) {                                                // :582-584
+                    unresolved = true;
+                    x = P.prev_xy[2 * qi]; y = P.prev_xy[2 * qi + 1];
+                    r = (float)P.window; minL = 0; maxL = 0;                              // :587
+                    qangle = F1->angle[qi];
+                }
+            } else {
+                qflags = QS->flags[qi];
+                if (qflags & ORBM_Q_VALID) {
+                    unresolved = true;
+                    x = QS->f0[qi]; y = QS->f1[qi];
+                    if (MODE == MODE_PROJ) {
+                        const int lvl = QS->l0[qi];
+                        float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;          // :168-174
+                        if (bFactor) rv = __fmul_rn(rv, P.th);                           // :84-85
+                        r = __fmul_rn(rv, F.sf[lvl]);                                    // :89
+                        minL = lvl - 1; maxL = lvl;
+                        xr = QS->f2[qi];
+                    } else {
+                        r = QS->f2[qi]; minL = QS->l0[qi]; maxL = QS->l1[qi];
+                        if (QS->f3) xr = QS->f3[qi];
+                        if (QS->angle) qangle = QS->angle[qi];
+                    }
+                }
+            }
+            if (unresolved)
+            {
+                const uint32_t *dsrc = MODE == MODE_INIT ? F1->desc : QS->desc;
+                const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
+                const uint4 lo = p4[0], hi = p4[1];
+                qd[0] = lo.x; qd[1] = lo.y; qd[2] = lo.z; qd[3] = lo.w; qd[4] = hi.x; qd[5] = hi.y; qd[6] = hi.z; qd[7] = hi.w;
+            }
+        }
+        const bool stereo_gate = MODE == MODE_PROJ || (MODE == MODE_LAST && QS->f3 != nullptr);
+        const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
+
+        int round = 0;
+        while (true) {
+            uint32_t *post = (round & 1) ? post1 : post0;
+            uint32_t *post_next = (round & 1) ? post0 : post1;
+            int bestDist = MODE == MODE_INIT ? INT_MAX : 256, bestDist2 = bestDist, bestIdx = -1;
+            int bestLevel = -1, bestLevel2 = -1;
+            // ---- evaluate ---------------------------------------------------------------------------
+            if (unresolved) {
+                auto body = [&](int k, int oct) {
+                    if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }      // :515-518
+                    const uint32_t st = state[k];
+                    if (MODE == MODE_PROJ || MODE == MODE_LAST) {
+                        if ((st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS)) return;          // :113-115 / :1879-1881
+                    } else if (MODE != MODE_INIT) {
+                        if (st & ORBM_MP_PRESENT) return;                                  // :2048 / :512
+                    }
+                    if (stereo_gate) {
+                        const float ur = F.uright[k];
+                        if (ur > 0) {
+                            const float er = fabsf(__fsub_rn(xr, ur));
+                            if (er > r) return;                                            // :117-122 / :1883-1891
+                        }
+                    }
+                    const uint4 *p4 = reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)k;
+                    const uint4 lo = p4[0], hi = p4[1];
+                    const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const int dist = (int)hamming256(qd, cd);
+                    if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                // :608
+                    if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                   // this query may still claim k
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = oct;
+                        bestIdx = k;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = oct; bestDist2 = dist;
+                    }
+                };
+                if (MODE == MODE_SIM3) walk_window<true>(F, x, y, r, minL, maxL, body);
+                else walk_window<false>(F, x, y, r, minL, maxL, body);
+            }
+            __syncthreads();
+            // ---- decide -----------------------------------------------------------------------------
+            if (unresolved) {
+                bool is_final = true;
+                auto chk = [&](int k, int oct) {
+                    if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
+                    if (post[k] < (uint32_t)tid) is_final = false;
+                };
+                if (MODE == MODE_SIM3) walk_window<true>(F, x, y, r, minL, maxL, chk);
+                else walk_window<false>(F, x, y, r, minL, maxL, chk);
+                if (is_final) {
+                    unresolved = false;
+                    bool accept;
+                    if (MODE == MODE_PROJ)
+                        accept = bestDist <= ORBM_TH_HIGH &&
+                                 !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2));  // :153-158
+                    else if (MODE == MODE_INIT)
+                        accept = bestDist <= ORBM_TH_LOW && (float)bestDist < __fmul_rn((float)bestDist2, P.ratio);    // :625-627
+                    else
+                        accept = bestDist <= thr;                                         // :1904 / :2062 / :533
+                    if (accept) {
+                        if (MODE == MODE_INIT) {
+                            const int old = owner[bestIdx];
+                            if (old >= 0) { out[old] = -1; my_matches--; }                 // :629-633
+                            out[qi] = bestIdx; owner[bestIdx] = qi; state[bestIdx] = (uint32_t)bestDist;  // :636-638
+                        } else {
+                            uint32_t ns = ORBM_MP_PRESENT;
+                            if ((MODE != MODE_PROJ && MODE != MODE_LAST) || (qflags & ORBM_Q_OBS)) ns |= ORBM_MP_OBS;
+                            state[bestIdx] = ns;
+                            owner[bestIdx] = qi;                                           // :160 / :1906 / :2066 / :535
+                        }
+                        my_matches++;
+                        if (use_hist) {
+                            const int bin = rot_bin(qangle, F.angle[bestIdx]);             // :644-651 / :1911-1918 / :2079-2090
+                            atomicAdd(&hist[bin], 1);
+                            if (MODE != MODE_INIT) atomicOr(&binmask[bestIdx], 1u << bin);
+                        }
+                    }
+                }
+            }
+            // reset the other post buffer for the next round (nobody reads it in this phase)
+            for (int i = tid; i < n; i += nthr) post_next[i] = NOPOST;
+            if (!__syncthreads_or(unresolved ? 1 : 0)) break;
+            round++;
+        }
+        // both post buffers must be clean for the next chunk: post (this round's) still holds entries
+        {
+            uint32_t *post = (round & 1) ? post1 : post0;
+            for (int i = tid; i < n; i += nthr) post[i] = NOPOST;
+        }
+        __syncthreads();
+    }
+
+    if (my_matches) atomicAdd(nmatch, my_matches);
+    __syncthreads();
+    if (use_hist) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+            // every accept event in a dropped bin is one nmatches-- (:1934-1946 / :2109-2119); MODE_INIT counts below
+            if (MODE != MODE_INIT) {
+                int drop = 0;
+                for (int b = 0; b < ORBM_HISTO_LENGTH; b++)
+                    if (b != i1 && b != i2 && b != i3) drop += hist[b];
+                *nmatch -= drop;
+            }
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        uint32_t keepmask = 0;
+        if (k1 >= 0) keepmask |= 1u << k1;
+        if (k2 >= 0) keepmask |= 1u << k2;
+        if (k3 >= 0) keepmask |= 1u << k3;
+        if (MODE == MODE_INIT) {
+            int removed = 0;
+            for (int i = tid; i < Q; i += nthr) {
+                const int m = out[i];
+                if (m < 0) continue;                                                      // :673 (a stolen match is already -1)
+                const int bin = rot_bin(F1->angle[i], F.angle[m]);
+                if (!((keepmask >> bin) & 1u)) { out[i] = -1; removed++; }
+            }
+            if (removed) atomicSub(nmatch, removed);
+        } else {
+            for (int i = tid; i < n; i += nthr)
+                if (binmask[i] & ~keepmask) owner[i] = -1;                                 // slot set to NULL
+        }
+        __syncthreads();
+    }
+    if (MODE == MODE_INIT) {
+        for (int i = tid; i < Q; i += nthr) {                                             // :684-686
+            const int m = out[i];
+            if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
+        }
+    } else {
+        for (int i = tid; i < n; i += nthr) out[i] = owner[i];
+    }
+    if (tid == 0) P.counts[inst] = *nmatch;
 }
-extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t, int32_t, float *, int, float, int, int32_t *) {
-    return orbm_fail(ctx, ORBM_EINVAL, "search_init: not built yet");
+
+size_t win_lds_bytes(int n) { return ((size_t)5 * n + 64) * 4; }
+
+template <int MODE>
+int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
+    const size_t lds = win_lds_bytes(max_n);
+    if (lds > 48 * 1024) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(window_kernel<MODE>, dim3(n_inst), dim3(threads), lds, ctx->stream, P);
+    HIPCHK(ctx, hipGetLastError());
+    return ORBM_OK;
+}
+
+int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n) {
+    const int threads = 512;
+    switch (mode) {
+        case MODE_LAST: return launch_mode<MODE_LAST>(ctx, P, n_inst, max_n, threads);
+        case MODE_KF: return launch_mode<MODE_KF>(ctx, P, n_inst, max_n, threads);
+        case MODE_SIM3: return launch_mode<MODE_SIM3>(ctx, P, n_inst, max_n, threads);
+        case MODE_INIT: return launch_mode<MODE_INIT>(ctx, P, n_inst, max_n, 256);
+        default: return launch_mode<MODE_PROJ>(ctx, P, n_inst, max_n, threads);
+    }
+}
+
+int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, const int32_t *qset, float th,
+                     float ratio, int dist_th, int check_ori, const uint8_t *slot_flags, int32_t stride,
+                     int32_t *owner, int32_t *counts, int io_on_device, const char *who) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_inst < 0 || (n_inst > 0 && (!frame || !qset || !owner || !counts)) || stride < 0)
+        return orbm_fail(ctx, ORBM_EINVAL, "%s: null argument or negative size", who);
+    if (n_inst == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int max_n = 0;
+    if (!io_on_device) {
+        int rc = orbm_check_frames(ctx, n_inst, frame, "frame");
+        if (!rc) rc = orbm_check_qsets(ctx, n_inst, qset, mode == MODE_PROJ ? 0 : 1, "qset");
+        if (rc) return rc;
+        for (int k = 0; k < n_inst; k++) max_n = std::max(max_n, ctx->h_frames[frame[k]].n);
+        if (max_n > stride) return orbm_fail(ctx, ORBM_EINVAL, "%s: stride %d < largest frame %d", who, stride, max_n);
+    } else {
+        max_n = stride;  // the caller's stride bounds every frame of the batch
+    }
+    if (max_n > WIN_MAX_N)
+        return orbm_fail(ctx, ORBM_ELIMIT, "%s: frames of more than %d keypoints are not supported by the windowed kernels (got %d)", who, WIN_MAX_N, max_n);
+    const size_t out_elems = (size_t)n_inst * stride;
+    IoStage io(ctx, io_on_device);
+    if (!io_on_device) {
+        int rc = orbm_ws_reserve(ctx, (size_t)n_inst * 12 + out_elems * 5 + 8192);
+        if (rc) return rc;
+    }
+    const void *dfr, *dqs, *dsf = nullptr; void *down, *dc;
+    int rc;
+    if ((rc = io.in(frame, (size_t)n_inst * 4, &dfr)) || (rc = io.in(qset, (size_t)n_inst * 4, &dqs)) ||
+        (rc = io.in(slot_flags, out_elems, &dsf)) || (rc = io.out(owner, out_elems * 4, &down)) ||
+        (rc = io.out(counts, (size_t)n_inst * 4, &dc)))
+        return rc;
+    if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(down, 0xFF, out_elems * 4, ctx->stream));
+    WinParams P;
+    memset(&P, 0, sizeof P);
+    P.frames = ctx->d_frames; P.qsets = ctx->d_qsets;
+    P.frame_ids = (const int32_t *)dfr; P.qset_ids = (const int32_t *)dqs;
+    P.slot_flags = (const uint8_t *)dsf;
+    P.out = (int32_t *)down; P.counts = (int32_t *)dc;
+    P.th = th; P.ratio = ratio; P.dist_th = dist_th; P.check_ori = check_ori; P.stride = stride;
+    rc = launch_window(ctx, mode, P, n_inst, std::max(max_n, 1));
+    if (rc) return rc;
+    return io.finish();
+}
+
+}  // namespace
+
+extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
+                                             float th, float ratio, const uint8_t *slot_flags, int32_t stride,
+                                             int32_t *owner, int32_t *counts, int io_on_device) {
+    return run_window_batch(ctx, MODE_PROJ, n_inst, frame, qset, th, ratio, ORBM_TH_HIGH, 0, slot_flags, stride, owner,
+                            counts, io_on_device, "search_proj_points_batch");
+}
+
+extern "C" int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame,
+                                        const int32_t *qset, int dist_th, int check_ori, const uint8_t *slot_flags,
+                                        int32_t stride, int32_t *owner, int32_t *counts, int io_on_device) {
+    if (ctx && (mode < 0 || mode > 2)) return orbm_fail(ctx, ORBM_EINVAL, "search_window_batch: mode must be 0, 1 or 2");
+    return run_window_batch(ctx, mode, n_inst, frame, qset, 1.0f, 1.0f, dist_th, check_ori, slot_flags, stride, owner,
+                            counts, io_on_device, "search_window_batch");
+}
+
+extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, float *prev_xy, int window, float ratio,
+                                int check_ori, int32_t *matches12) {
+    if (!ctx) return ORBM_EINVAL;
+    int rc = orbm_check_frames(ctx, 1, &frame1, "frame1");
+    if (!rc) rc = orbm_check_frames(ctx, 1, &frame2, "frame2");
+    if (rc) return rc;
+    const int n1 = ctx->h_frames[frame1].n, n2 = ctx->h_frames[frame2].n;
+    if (n1 > 0 && (!prev_xy || !matches12)) return orbm_fail(ctx, ORBM_EINVAL, "search_init: null argument");
+    if (n1 == 0) return 0;
+    if (n2 > WIN_MAX_N) return orbm_fail(ctx, ORBM_ELIMIT, "search_init: frame 2 has %d keypoints (limit %d)", n2, WIN_MAX_N);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rc = orbm_ws_reserve(ctx, (size_t)n1 * 12 + 4096);
+    if (rc) return rc;
+    char *w = (char *)ctx->ws;
+    int32_t *d_ids = (int32_t *)w;                 // [frame2, frame1]
+    int32_t *d_count = (int32_t *)(w + 256);
+    float *d_prev = (float *)(w + 512);
+    int32_t *d_m12 = (int32_t *)(w + 512 + (((size_t)n1 * 8 + 255) / 256) * 256);
+    const int32_t ids[2] = {frame2, frame1};
+    HIPCHK(ctx, hipMemcpyAsync(d_ids, ids, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_prev, prev_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, ctx->stream));
+    WinParams P;
+    memset(&P, 0, sizeof P);
+    P.frames = ctx->d_frames; P.qsets = ctx->d_qsets;
+    P.frame_ids = d_ids; P.qset_ids = d_ids + 1;
+    P.prev_xy = d_prev; P.out = d_m12; P.counts = d_count;
+    P.th = 1.0f; P.ratio = ratio; P.dist_th = ORBM_TH_LOW; P.check_ori = check_ori; P.stride = n1; P.window = window;
+    rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1));
+    if (rc) return rc;
+    int32_t count = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(prev_xy, d_prev, (size_t)n1 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(matches12, d_m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return count;
 }

@@ -1,0 +1,207 @@
+"""GPU parity of the search kernels through the C ABI against the CPU oracle (bit-exact):
+a7/a8 SearchByBoW, a9 SearchForTriangulation, a6 SearchByProjection(F, MapPoints), a11 windowed best-1
+overloads, a5 SearchForInitialization."""
+import numpy as np
+import pytest
+
+from orbslam2_amd import synth
+from orbslam2_amd.views import MP_PRESENT, MP_OBS, MP_BAD, FrameData, ProjQueries
+
+pytestmark = pytest.mark.gpu
+
+
+def contended_pool(seed, n_kf, n, n_lm, **kw):
+    """Keyframes whose keypoints re-observe a SMALL landmark pool: many keypoints of one keyframe share a
+    landmark, so several queries want the same candidate and the in-order claim rules decide."""
+    rng = np.random.default_rng(seed)
+    lm_desc = synth.random_descriptors(rng, n_lm)
+    frames = []
+    for _ in range(n_kf):
+        lm = rng.integers(0, n_lm, n)
+        flags = np.where(rng.random(n) < kw.get("valid", 0.9), MP_PRESENT | MP_OBS, 0).astype(np.uint8)
+        flags[(rng.random(n) < kw.get("bad", 0.05)) & (flags != 0)] |= MP_BAD
+        ur = np.where(rng.random(n) < 0.3, rng.uniform(1, 600, n), -1.0).astype(np.float32)
+        frames.append(synth.make_frame(rng, lm_desc, lm, mp_flags=flags, uright=ur, p_flip=kw.get("p_flip", 0.05),
+                                       n_nodes=kw.get("n_nodes", 20), octave=rng.integers(0, 8, n).astype(np.int32)))
+    return frames
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_bow_parity_pool(ctx, orc, variant, check_ori):
+    kfs = synth.keyframe_pool(seed=synth.SEED0 + 4, n_kf=6, n=2000)
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.triu_indices(6, 1)
+    counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, check_ori, stride=2000)
+    tot = 0
+    for k, (i, j) in enumerate(zip(pa, pb)):
+        wc, wm, _ = orc.search_bow(variant, kfs[i], kfs[j], 0.75, check_ori)
+        assert counts[k] == wc, (i, j, counts[k], wc)
+        assert np.array_equal(match[k], wm), (i, j)
+        tot += wc
+    assert tot > 1000
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_bow_parity_contended_claims(ctx, orc, variant):
+    kfs = contended_pool(11 + variant, 5, 700, 150) + contended_pool(21, 2, 300, 10, n_nodes=2)  # nodes > 64 wide
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.meshgrid(np.arange(len(kfs)), np.arange(len(kfs)))
+    pa, pb = pa.ravel(), pb.ravel()          # includes a keyframe against itself
+    counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.9, True, stride=700)
+    for k, (i, j) in enumerate(zip(pa, pb)):
+        wc, wm, _ = orc.search_bow(variant, kfs[i], kfs[j], 0.9, True)
+        n_out = kfs[j].n if variant == 0 else kfs[i].n
+        assert counts[k] == wc, (i, j, counts[k], wc)
+        assert np.array_equal(match[k, :n_out], wm), (i, j)
+    ctx.free_frames(ids)
+
+
+def test_bow_empty_and_disjoint(ctx, orc):
+    rng = np.random.default_rng(3)
+    lm = synth.random_descriptors(rng, 100)
+    fl = np.full(50, MP_PRESENT | MP_OBS, np.uint8)
+    a = synth.make_frame(rng, lm, np.arange(50), mp_flags=fl)
+    b = synth.make_frame(rng, lm, np.arange(50, 100), mp_flags=fl)   # other landmarks: nodes mostly differ
+    e = synth.make_frame(rng, lm, np.arange(0), mp_flags=np.zeros(0, np.uint8))
+    ids = ctx.upload_frames([a, b, e])
+    for variant in (0, 1):
+        for (i, j) in ((0, 1), (0, 2), (2, 0), (2, 2), (0, 0)):
+            fr = [a, b, e]
+            counts, match = ctx.search_bow(variant, [ids[i]], [ids[j]], 0.75, True, stride=50)
+            wc, wm, _ = orc.search_bow(variant, fr[i], fr[j], 0.75, True)
+            assert counts[0] == wc
+            assert np.array_equal(match[0, :len(wm)], wm)
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("only_stereo,check_ori", [(False, False), (False, True), (True, False)])
+def test_triang_parity(ctx, orc, only_stereo, check_ori):
+    cases = [synth.triang_pair(50 + s, n=1500) for s in range(3)]
+    frames = [f for c in cases for f in c[:2]]
+    ids = ctx.upload_frames(frames)
+    fa, fb = ids[0::2], ids[1::2]
+    f12 = np.stack([c[2] for c in cases]); ep = np.stack([c[3] for c in cases])
+    counts, match = ctx.search_triang(fa, fb, f12, ep, only_stereo, check_ori, stride=1500)
+    tot = 0
+    for k, c in enumerate(cases):
+        wc, wm, _ = orc.search_triang(c[0], c[1], c[2], c[3], only_stereo, check_ori)
+        assert counts[k] == wc
+        assert np.array_equal(match[k], wm)
+        tot += wc
+    assert tot > (10 if only_stereo else 200)
+    ctx.free_frames(ids)
+
+
+def test_triang_last_wins_on_equal_distance(ctx, orc):
+    """dist > bestDist skips, so an equal distance REPLACES (ORBmatcher.cc:993): duplicate candidates."""
+    f1, f2, f12, ep = synth.triang_pair(99, n=400, stereo_frac=1.0, has_mp_frac=0.0)
+    # make every f2 keypoint appear twice (same descriptor, same position, same node)
+    dup = FrameData(desc=np.concatenate([f2.desc, f2.desc]), x=np.concatenate([f2.x, f2.x]), y=np.concatenate([f2.y, f2.y]),
+                    angle=np.concatenate([f2.angle, f2.angle]), octave=np.concatenate([f2.octave, f2.octave]),
+                    uright=np.concatenate([f2.uright, f2.uright]), mp_flags=np.zeros(800, np.uint8))
+    node = np.zeros(400, np.uint32)
+    for k in range(len(f2.fv_node)):
+        node[f2.fv_idx[f2.fv_off[k]:f2.fv_off[k + 1]]] = f2.fv_node[k]
+    dup.fv_node, dup.fv_off, dup.fv_idx = synth.feature_vector(np.concatenate([node, node]))
+    ids = ctx.upload_frames([f1, dup])
+    counts, match = ctx.search_triang([ids[0]], [ids[1]], f12[None], ep[None], False, False, stride=400)
+    wc, wm, _ = orc.search_triang(f1, dup, f12, ep, False, False)
+    assert counts[0] == wc and np.array_equal(match[0], wm)
+    assert (wm >= 400).sum() > 50          # the later duplicate is the one reported
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0, 5.0])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_proj_points_parity(ctx, orc, th, stereo):
+    f, q = synth.proj_instance(seed=300 + int(th) + 10 * stereo, n=2000, n_queries=6000, stereo=stereo,
+                               claimed_frac=0.2, obs_frac=0.8, valid_frac=0.9)
+    fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+    counts, owner = ctx.search_proj_points(fid, qid, th, 0.8, stride=2000)
+    wc, wo, ncmp = orc.search_proj_points(f, q, th, 0.8)
+    assert counts[0] == wc and wc > 500
+    assert np.array_equal(owner[0], wo)
+    ctx.free_frames(fid); ctx.free_queries(qid)
+
+
+def test_proj_points_batch_with_slot_flags_and_edges(ctx, orc):
+    insts = [synth.proj_instance(seed=400 + k, n=[2000, 1, 700, 64][k], n_queries=[5000, 10, 0, 3000][k],
+                                 claimed_frac=0.1, obs_frac=0.5) for k in range(4)]
+    # queries far outside the image and on the border cells
+    insts[3][1].proj_x[:50] = np.linspace(-300, 900, 50, dtype=np.float32)
+    insts[3][1].proj_y[:50] = np.linspace(900, -300, 50, dtype=np.float32)
+    fids = ctx.upload_frames([i[0] for i in insts]); qids = ctx.upload_proj_queries([i[1] for i in insts])
+    rng = np.random.default_rng(9)
+    slot = np.zeros((4, 2000), np.uint8)
+    slot[rng.random((4, 2000)) < 0.3] = MP_PRESENT | MP_OBS
+    slot[rng.random((4, 2000)) < 0.1] = MP_PRESENT
+    counts, owner = ctx.search_proj_points(fids, qids, 3.0, 0.8, stride=2000, slot_flags=slot)
+    for k, (f, q) in enumerate(insts):
+        wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8, slot_flags=slot[k, :f.n])
+        assert counts[k] == wc
+        assert np.array_equal(owner[k, :f.n], wo)
+        assert (owner[k, f.n:] == -1).all()
+    ctx.free_frames(fids); ctx.free_queries(qids)
+
+
+def test_proj_points_heavy_contention(ctx, orc):
+    """Many queries per keypoint, unsorted, large windows: long claim chains inside a chunk."""
+    f, q = synth.proj_instance(seed=555, n=300, n_queries=20000, th_noise=6.0, obs_frac=0.6)
+    fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+    for th in (5.0, 1.0):
+        counts, owner = ctx.search_proj_points(fid, qid, th, 0.9, stride=300)
+        wc, wo, _ = orc.search_proj_points(f, q, th, 0.9)
+        assert counts[0] == wc and np.array_equal(owner[0], wo)
+    ctx.free_frames(fid); ctx.free_queries(qid)
+
+
+@pytest.mark.parametrize("mode,dist_th", [(0, 100), (1, 100), (1, 64), (2, 50)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_window_parity(ctx, orc, mode, dist_th, check_ori):
+    insts = [synth.window_instance(700 + 10 * mode + k, mode, n=[2000, 500, 1][k], n_queries=[3000, 4000, 5][k],
+                                   stereo=(k == 0), claimed_frac=0.15) for k in range(3)]
+    fids = ctx.upload_frames([i[0] for i in insts]); qids = ctx.upload_win_queries([i[1] for i in insts])
+    counts, owner = ctx.search_window(mode, fids, qids, dist_th, check_ori, stride=2000)
+    tot = 0
+    for k, (f, q) in enumerate(insts):
+        wc, wo, _ = orc.search_window(mode, f, q, dist_th, check_ori)
+        assert counts[k] == wc, (k, counts[k], wc)
+        assert np.array_equal(owner[k, :f.n], wo)
+        tot += wc
+    assert tot > 300
+    ctx.free_frames(fids); ctx.free_queries(qids)
+
+
+@pytest.mark.parametrize("n,window,ratio,check_ori", [(1000, 100, 0.9, True), (1000, 10, 0.9, True),
+                                                      (2000, 100, 0.9, False), (300, 400, 0.95, True)])
+def test_search_init_parity(ctx, orc, n, window, ratio, check_ori):
+    f1, f2, prev = synth.init_pair(seed=synth.SEED0 + 1 + n, n=n)
+    ids = ctx.upload_frames([f1, f2])
+    cnt, m12, prev_out = ctx.search_init(ids[0], ids[1], prev, window, ratio, check_ori)
+    wc, wm, wprev, ncmp = orc.search_init(f1, f2, prev, window, ratio, check_ori)
+    assert cnt == wc
+    assert np.array_equal(m12, wm)
+    assert np.array_equal(prev_out, wprev)
+    if window >= 100:
+        assert wc > 20
+    ctx.free_frames(ids)
+
+
+def test_search_init_steals(ctx, orc):
+    """Several F1 keypoints see the same F2 keypoint: a later, closer one steals it (ORBmatcher.cc:629-633)."""
+    rng = np.random.default_rng(8)
+    lm = synth.random_descriptors(rng, 50)
+    n = 400
+    oct0 = np.zeros(n, np.int32)
+    f2 = synth.make_frame(rng, lm, rng.integers(0, 50, n), with_fv=False, octave=oct0, p_flip=0.03,
+                          x=rng.uniform(100, 200, n).astype(np.float32), y=rng.uniform(100, 200, n).astype(np.float32))
+    f1 = synth.make_frame(rng, lm, rng.integers(0, 50, n), with_fv=False, octave=oct0, p_flip=0.03,
+                          x=rng.uniform(100, 200, n).astype(np.float32), y=rng.uniform(100, 200, n).astype(np.float32))
+    prev = np.stack([f1.x, f1.y], 1)
+    ids = ctx.upload_frames([f1, f2])
+    cnt, m12, prev_out = ctx.search_init(ids[0], ids[1], prev, 150, 1.5, True)
+    wc, wm, wprev, _ = orc.search_init(f1, f2, prev, 150, 1.5, True)
+    assert cnt == wc and np.array_equal(m12, wm) and np.array_equal(prev_out, wprev)
+    ctx.free_frames(ids)
