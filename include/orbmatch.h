@@ -119,7 +119,8 @@ typedef struct orbm_ctx orbm_ctx;
 orbm_ctx *orbm_create(int device);           /* NULL on failure (orbm_last_error(NULL) has the text) */
 void orbm_destroy(orbm_ctx *ctx);
 const char *orbm_last_error(const orbm_ctx *ctx);
-int orbm_set_stream(orbm_ctx *ctx, void *hip_stream); /* adopt a caller stream (NULL = own stream) */
+/* adopt a caller's hipStream_t (NULL is the HIP null stream); (void*)-1 returns to the context's own stream */
+int orbm_set_stream(orbm_ctx *ctx, void *hip_stream);
 int orbm_synchronize(orbm_ctx *ctx);
 int orbm_device_info(orbm_ctx *ctx, int32_t *n_cu, int32_t *clock_khz, char *name, int name_len);
 

@@ -1,13 +1,23 @@
 // bf2nn.hip -- brute-force 2-NN + threshold + ratio test over keyframe pairs (BASELINE config 2 and the
-// brute-force variant of config 5).  Integer-VALU (popcount) bound: 8 v_xor_b32 + 8 v_bcnt_u32_b32 per
-// 256-bit comparison plus 3 tracking ops (v_lshl_or_b32 key, v_med3_u32 second, v_min_u32 best).
+// brute-force variant of config 5).  Integer-VALU (popcount) bound.
 //
-// Work decomposition: one 256-thread workgroup owns 256*R consecutive query rows of frame a (R rows per
-// lane, 8 VGPRs each) and walks ALL candidate rows of frame b in ascending index.  Candidate rows are
-// staged global -> LDS in coalesced 16-byte loads, TILE rows at a time; every lane then reads the same
-// LDS row (broadcast ds_read_b128 x2) and reuses it for its R queries.  Since each lane sees the
-// candidates in the reference's visit order, key = (dist << 16) | j reproduces the strict-< first-wins
-// rule of ORBmatcher.cc:290-300, and second-best is the median of (best, second, key).
+// Measured on gfx950 (scripts/ubench_valu2.hip): v_xor/v_and/v_or/v_add issue in ~2 cycles per wave64
+// instruction, v_bcnt_u32_b32 / v_min_u32 / v_med3_u32 / v_lshl_or_b32 / v_cmp in ~4.  One 256-bit
+// comparison needs 8 xor + 8 bcnt no matter what; everything else is overhead, so the inner loop keeps
+// the per-comparison extras down to ONE fast op:
+//   * each lane owns R query rows in VGPRs and walks ALL candidate rows in ascending index, so the
+//     reference's visit order (strict-< first-wins, ORBmatcher.cc:290-300) is the loop order;
+//   * the popcount chain starts from bias = 0x80000000 - second_best instead of 0, so bit 31 of the
+//     result is CLEAR exactly when dist < second_best, i.e. when the reference's update would fire;
+//   * a group of U candidates x R queries is AND-ed into one mask; only if some lane of the wave has a
+//     clear bit 31 does the wave take the (rare) exact update: key = (dist << 16) | j,
+//     second = med3(best, second, key), best = min(best, key);
+//   * when the caller does not ask for the raw distances, candidates at distance >= track_below can never
+//     change the outcome of "best <= th && (float)best < ratio*(float)second" (track_below is the smallest
+//     T > th with (float)th < ratio*(float)T), so the bias is capped at track_below and the exact update
+//     only fires for candidates that can matter.  All nA x nB distances are still evaluated.
+// Candidate rows are staged global -> LDS in coalesced 16-byte loads, TILE rows at a time; all lanes read
+// the same LDS row (broadcast ds_read_b128 x2) and reuse it for their R queries.
 #include <string.h>
 #include <algorithm>
 #include "orbm_internal.h"
@@ -15,12 +25,28 @@
 namespace {
 
 constexpr int BF_TILE = 512;  // candidate rows per LDS tile (16 KB)
-constexpr int BF_UNROLL = 4;
+constexpr int BF_R = 2;       // query rows per lane   (R2/U4: 47 VGPRs, 8 waves per SIMD; fastest of the
+constexpr int BF_U = 4;       // candidate rows per group  variants A/B-ed in scripts/bf_variants.py)
 
-template <int R>
+// popcount chain seeded with `bias`: returns bias + hamming(a, b)
+__device__ __forceinline__ uint32_t hamming256_biased(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t bias) {
+    uint32_t d;
+    {
+        const uint32_t x = a[0] ^ b[0];
+        asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(bias));
+    }
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        const uint32_t x = a[i] ^ b[i];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    return d;
+}
+
+template <int R, int U, int DIAG>
 __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__ table,
                                                     const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
-                                                    int blocks_per_pair, float ratio, int th, int stride,
+                                                    int blocks_per_pair, float ratio, int th, int track_below, int stride,
                                                     int32_t *__restrict__ match, int32_t *__restrict__ best_d,
                                                     int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
     __shared__ uint4 tile[BF_TILE * 2];
@@ -35,7 +61,7 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
     if (qb * (256 * R) >= nA) return;  // whole block idle (uniform)
 
     uint32_t q[R][8];
-    uint32_t best[R], second[R];
+    uint32_t best[R], second[R], bias[R];
     const uint4 *Ad = reinterpret_cast<const uint4 *>(A.desc);
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -46,6 +72,7 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
         q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
         best[r] = (256u << 16) | 0xFFFFu;   // bestDist1 = 256, bestIdx = -1  (ORBmatcher.cc:271-273)
         second[r] = (256u << 16) | 0xFFFFu; // bestDist2 = 256
+        bias[r] = 0x80000000u - (uint32_t)min(256, track_below);
     }
 
     const uint4 *Bd = reinterpret_cast<const uint4 *>(B.desc);
@@ -54,26 +81,48 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
         __syncthreads();
         for (int i = tid; i < rows * 2; i += 256) tile[i] = Bd[t0 * 2 + i];
         __syncthreads();
-        // inline asm is convergent in HIP, so a runtime-trip-count loop is not unrolled by hipcc: unroll
-        // by hand (constant inner trip count) and finish the tail one row at a time.
-        auto step = [&](int j) {
+        int j = 0;
+        for (; j + U <= rows; j += U) {
+            uint32_t acc[U][R];
+            uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint4 c0 = tile[2 * (j + u)], c1 = tile[2 * (j + u) + 1];
+                const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    acc[u][r] = hamming256_biased(q[r], c, bias[r]);
+                    m &= acc[u][r];
+                }
+            }
+            // DIAG 1: never update (timing floor, wrong results); DIAG 2: always update (v1 behaviour)
+            if (DIAG != 1 && (DIAG == 2 || __any((int)m >= 0))) {  // some lane saw dist < second best: exact update for the whole group
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t jj = (uint32_t)(t0 + j + u);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const uint32_t key = ((acc[u][r] - bias[r]) << 16) | jj;
+                        second[r] = umed3(best[r], second[r], key);
+                        best[r] = min(best[r], key);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) bias[r] = 0x80000000u - min(second[r] >> 16, (uint32_t)track_below);
+            }
+        }
+        for (; j < rows; j++) {  // tail of the tile
             const uint4 c0 = tile[2 * j], c1 = tile[2 * j + 1];
             const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             const uint32_t jj = (uint32_t)(t0 + j);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t d = hamming256(q[r], c);
-                const uint32_t key = (d << 16) | jj;
+                const uint32_t key = (hamming256(q[r], c) << 16) | jj;
                 second[r] = umed3(best[r], second[r], key);
                 best[r] = min(best[r], key);
+                bias[r] = 0x80000000u - min(second[r] >> 16, (uint32_t)track_below);
             }
-        };
-        int j = 0;
-        for (; j + BF_UNROLL <= rows; j += BF_UNROLL) {
-#pragma unroll
-            for (int u = 0; u < BF_UNROLL; u++) step(j + u);
         }
-        for (; j < rows; j++) step(j);
     }
 
     int accepted = 0;
@@ -96,7 +145,12 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
     if ((tid & 63) == 0 && accepted) atomicAdd(&counts[p], accepted);
 }
 
+int g_bf_variant = 0;
+
 }  // namespace
+
+// tuning / diagnostic knob used by scripts/ (not part of the public ABI)
+extern "C" void orbm__bf2nn_variant(int v) { g_bf_variant = v; }
 
 extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                                 float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
@@ -138,13 +192,31 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         return rc;
     HIPCHK(ctx, hipMemsetAsync(dc, 0, (size_t)n_pairs * 4, ctx->stream));
     if (!io_on_device) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));  // rows beyond n stay -1
-    constexpr int R = 2;
+    // smallest distance that can never influence the accept decision (see kernel header); 257 = track all
+    int track_below = 257;
+    if (!best_d && !second_d && g_bf_variant != 7) {
+        for (int t = std::max(th + 1, 1); t <= 256; t++)
+            if ((float)th < ratio * (float)t) { track_below = t; break; }
+    }
+    const int variant = g_bf_variant;
+    const int R = (variant == 0 || variant == 3 || variant >= 7 || variant < 0) ? 2 : 4;
     const int bpp = (max_na + 256 * R - 1) / (256 * R);
     const long long grid = (long long)n_pairs * bpp;
     if (grid > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
-    hipLaunchKernelGGL(bf2nn_kernel<R>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->d_frames,
-                       (const int32_t *)dfa, (const int32_t *)dfb, bpp, ratio, th, stride, (int32_t *)dm,
-                       (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
+#define BF_LAUNCH(RR, UU, DD)                                                                                   \
+    hipLaunchKernelGGL((bf2nn_kernel<RR, UU, DD>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->d_frames, \
+                       (const int32_t *)dfa, (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, \
+                       (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
+    switch (variant) {
+        case 1: BF_LAUNCH(4, 2, 0); break;
+        case 2: BF_LAUNCH(4, 1, 0); break;
+        case 3: BF_LAUNCH(2, 2, 0); break;
+        case 4: BF_LAUNCH(4, 2, 1); break;   // diagnostic: no exact updates (results wrong)
+        case 5: BF_LAUNCH(4, 2, 2); break;   // diagnostic: exact update on every group
+        case 6: BF_LAUNCH(4, 4, 0); break;
+        default: BF_LAUNCH(BF_R, BF_U, 0); break;
+    }
+#undef BF_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }

@@ -233,7 +233,7 @@ const char *orbm_last_error(const orbm_ctx *ctx) { return ctx ? ctx->err.c_str()
 int orbm_set_stream(orbm_ctx *ctx, void *hip_stream) {
     if (!ctx) return ORBM_EINVAL;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = hip_stream == (void *)-1 ? ctx->own_stream : (hipStream_t)hip_stream;
     return ORBM_OK;
 }
 

@@ -53,7 +53,11 @@ class Context:
 
     # ---- context ----
     def set_stream(self, hip_stream: Optional[int]):
-        self._chk(self._L.orbm_set_stream(self._h, hip_stream))
+        """Adopt a caller stream (0 / None = the HIP null stream, e.g. torch's default stream)."""
+        self._chk(self._L.orbm_set_stream(self._h, hip_stream or None))
+
+    def use_own_stream(self):
+        self._chk(self._L.orbm_set_stream(self._h, C.c_void_p(-1)))
 
     def synchronize(self):
         self._chk(self._L.orbm_synchronize(self._h))

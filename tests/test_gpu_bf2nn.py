@@ -99,3 +99,20 @@ def test_errors_are_loud(ctx):
     from orbslam2_amd.matcher import OrbmError
     with pytest.raises(OrbmError):
         ctx.bf2nn([12345], [0], 0.75, 50, stride=10)
+
+
+@pytest.mark.parametrize("ratio,th", [(0.75, 50), (0.6, 50), (0.9, 100), (1.5, 50), (0.75, 300), (0.0, 50), (0.75, -1)])
+def test_bf2nn_matches_only_path(ctx, orc, ratio, th):
+    """Without the raw-distance outputs the kernel caps its tracking at the acceptance bound; matches and
+    counts must not change (2000x2000 is BASELINE config 2; 515x1031 exercises the tile tail)."""
+    for (na, nb, seed) in ((2000, 2000, 1), (515, 1031, 2)):
+        rng = np.random.default_rng(seed)
+        a, b = synth.bf_pair(seed=seed, n=max(na, nb))
+        fa = synth.make_frame(rng, a.desc, np.arange(na), with_fv=False, p_flip=0.0)
+        fb = synth.make_frame(rng, b.desc, np.arange(nb), with_fv=False, p_flip=0.0)
+        ids = ctx.upload_frames([fa, fb])
+        counts, match, _, _ = ctx.bf2nn([ids[0]], [ids[1]], ratio, th, stride=na, want_dist=False)
+        wc, wm, _, _, _ = orc.bf2nn(fa, fb, ratio, th)
+        assert counts[0] == wc
+        assert np.array_equal(match[0], wm)
+        ctx.free_frames(ids)

@@ -1,0 +1,203 @@
+"""Known-answer tests that pin the CPU oracle (oracle/orb_oracle.cpp).
+
+The reference ships no tests or golden vectors for this path (parity unpinned), so the
+oracle is pinned by hand-checkable answers derived from the reference's source lines, and by a slow
+pure-numpy restatement of the same lines on small random cases."""
+import numpy as np
+import pytest
+
+from orbslam2_amd import synth
+from orbslam2_amd.views import FrameData, ProjQueries, MP_PRESENT, MP_OBS, MP_BAD, Q_VALID, Q_OBS, GRID_ROWS
+
+
+def _desc(bits):
+    d = np.zeros(256, np.uint8)
+    d[list(bits)] = 1
+    return np.packbits(d, bitorder="little")
+
+
+def test_descriptor_distance_known_answers(orc):
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert orc.hamming256(z, o) == 256 and orc.hamming256(o, z) == 256
+    assert orc.hamming256(z, z) == 0 and orc.hamming256(o, o) == 0
+    for bit in (0, 1, 31, 32, 63, 128, 255):
+        assert orc.hamming256(z, _desc([bit])) == 1
+    assert orc.hamming256(_desc(range(0, 256, 2)), _desc(range(1, 256, 2))) == 256
+    assert orc.hamming256(_desc(range(10)), _desc(range(5, 15))) == 10
+    rng = np.random.default_rng(0)
+    a, b = synth.random_descriptors(rng, 500), synth.random_descriptors(rng, 500)
+    want = np.unpackbits(a ^ b, axis=1).sum(1)
+    for i in range(500):
+        assert orc.hamming256(a[i], b[i]) == want[i] == orc.hamming256(a[i], b[i], popcnt=True)
+
+
+def test_three_maxima_known_answers(orc):
+    # ORBmatcher.cc:2135-2178; expectations of SURVEY 8c
+    h = np.zeros(30, np.int32)
+    assert orc.three_maxima(h) == (-1, -1, -1)
+    h[:3] = 5
+    assert orc.three_maxima(h) == (0, 1, 2)            # ties: lower bin ranks higher
+    h = np.zeros(30, np.int32); h[0], h[1], h[2] = 100, 9, 9
+    assert orc.three_maxima(h) == (0, -1, -1)          # max2 < 0.1*max1 drops 2 and 3
+    h[1] = 10
+    assert orc.three_maxima(h) == (0, 1, -1)           # 10 is not < 10.0; 9 is
+    h = np.zeros(30, np.int32); h[7], h[3], h[29] = 3, 8, 5
+    assert orc.three_maxima(h) == (3, 29, 7)
+
+
+def test_rotation_bin_known_answers(orc):
+    # ORBmatcher.cc:323-328 with factor = 1/30: only bins 0..12 are ever produced
+    assert orc.rot_bin(10.0, 350.0) == 1               # rot = -340 + 360 = 20 -> round(0.666) = 1
+    assert orc.rot_bin(350.0, 10.0) == 11              # 340/30 = 11.33
+    assert orc.rot_bin(0.0, 0.0) == 0
+    assert orc.rot_bin(359.9, 0.0) == 12
+    assert orc.rot_bin(15.0, 0.0) == 1                 # 0.5 rounds away from zero
+    assert orc.rot_bin(14.9, 0.0) == 0
+    assert max(orc.rot_bin(a, b) for a in np.linspace(0, 359.99, 97) for b in np.linspace(0, 359.99, 89)) == 12
+
+
+def test_grid_uses_round_not_floor(orc):
+    # Frame.cc:510-511: posX = round((x-minX)*inv); 640x480 -> inv = 0.1; x = 5 -> cell 1 (0.5 rounds up), 4.9 -> 0
+    f = FrameData(desc=np.zeros((4, 32), np.uint8), x=[4.9, 5.0, 634.9, 635.0], y=[0.0, 14.9, 475.0, 10.0],
+                  angle=np.zeros(4), octave=np.zeros(4, np.int32))
+    off, idx = orc.build_grid(f)
+    cell = {int(k): c for c in range(len(off) - 1) for k in idx[off[c]:off[c + 1]]}
+    assert cell[0] == 0 * GRID_ROWS + 0
+    assert cell[1] == 1 * GRID_ROWS + 1
+    assert 2 not in cell                                # y = 475 -> round(47.5) = 48 -> outside, dropped
+    assert 3 not in cell                                # x = 635 -> round(63.5) = 64 -> outside, dropped
+    assert len(idx) == 2
+
+
+def test_features_in_area_order_and_levels(orc):
+    # visit order: ix ascending, then iy ascending, then insertion order (Frame.cc:462-493)
+    x = np.array([52.0, 41.0, 41.0, 58.0, 47.0], np.float32)
+    y = np.array([52.0, 58.0, 41.0, 41.0, 47.0], np.float32)
+    f = FrameData(desc=np.zeros((5, 32), np.uint8), x=x, y=y, angle=np.zeros(5), octave=np.array([0, 1, 2, 3, 0], np.int32))
+    got = orc.features_in_area(f, 50.0, 50.0, 10.0)
+    assert list(got) == [2, 1, 0, 4, 3]                 # cells (4,4) (4,6) | (5,5): kp0 then kp4 | (6,4)
+    assert list(orc.features_in_area(f, 50.0, 50.0, 10.0, 1, 2)) == [2, 1]
+    assert list(orc.features_in_area(f, 50.0, 50.0, 10.0, 1, -1)) == [2, 1, 3]      # minLevel only
+    assert list(orc.features_in_area(f, 50.0, 50.0, 10.0, 0, 0)) == [0, 4]          # bCheckLevels via maxLevel>=0
+    assert list(orc.features_in_area(f, 50.0, 50.0, 10.0, 1, 2, kf_mode=True)) == [2, 1, 0, 4, 3]
+    assert list(orc.features_in_area(f, 50.0, 50.0, 8.0)) == [0, 4]                 # |dx| < r strict: 58-50 = 8 excluded
+    assert len(orc.features_in_area(f, 5000.0, 50.0, 10.0)) == 0
+    assert len(orc.features_in_area(f, -5000.0, 50.0, 10.0)) == 0
+
+
+def _two_frames(dq, dc):
+    nq, nc = len(dq), len(dc)
+    mk = lambda d, n: FrameData(desc=d, x=np.full(n, 100.0), y=np.full(n, 100.0), angle=np.zeros(n),
+                                octave=np.zeros(n, np.int32))
+    return mk(np.array(dq), nq), mk(np.array(dc), nc)
+
+
+def test_bf2nn_tie_break_known_answers(orc):
+    q = _desc(range(40))
+    c_far = _desc(range(100, 228))
+    c_d1a = _desc(list(range(40)) + [200])
+    c_d1b = _desc(list(range(40)) + [201])
+    fa, fb = _two_frames([q], [c_far, c_d1a, c_d1b])
+    cnt, match, bd, sd, ncmp = orc.bf2nn(fa, fb, 0.9, 50)
+    assert (bd[0], sd[0], match[0], cnt, ncmp) == (1, 1, -1, 0, 3)   # duplicate best distance = second best -> ratio fails
+    cnt, match, bd, sd, _ = orc.bf2nn(fa, fb, 1.5, 50)
+    assert match[0] == 1                                             # first seen wins the tie
+    fa, fb = _two_frames([q], [c_far])
+    cnt, match, bd, sd, _ = orc.bf2nn(fa, fb, 0.9, 50)
+    assert (bd[0], sd[0], match[0]) == (168, 256, -1)
+    fa, fb = _two_frames([q], [c_d1a, c_far])
+    assert orc.bf2nn(fa, fb, 0.9, 50)[1][0] == 0                     # 1 < 0.9*168
+
+
+def _numpy_search_bow(variant, A, B, ratio, check_ori):
+    """Slow, independent restatement of ORBmatcher.cc:218-385 / 703-854 used to cross-check the C++ oracle."""
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    n_out = B.n if variant == 0 else A.n
+    match = np.full(n_out, -1, np.int64)
+    claimed = np.zeros(B.n, bool)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    nodesB = {int(n): k for k, n in enumerate(B.fv_node)}
+    fa = A.mp_flags if A.mp_flags is not None else np.zeros(A.n, np.uint8)
+    fb = B.mp_flags if B.mp_flags is not None else np.zeros(B.n, np.uint8)
+    angB = B.angle_raw if (variant == 0 and B.angle_raw is not None) else B.angle
+    for ka, node in enumerate(A.fv_node):
+        kb = nodesB.get(int(node))
+        if kb is None:
+            continue
+        for ia in A.fv_idx[A.fv_off[ka]:A.fv_off[ka + 1]]:
+            if not (fa[ia] & MP_PRESENT) or (fa[ia] & MP_BAD):
+                continue
+            b1, b2, bi = 256, 256, -1
+            for ib in B.fv_idx[B.fv_off[kb]:B.fv_off[kb + 1]]:
+                if claimed[ib]:
+                    continue
+                if variant == 1 and (not (fb[ib] & MP_PRESENT) or (fb[ib] & MP_BAD)):
+                    continue
+                d = ham(A.desc[ia], B.desc[ib])
+                if d < b1:
+                    b2, b1, bi = b1, d, int(ib)
+                elif d < b2:
+                    b2 = d
+            ok = b1 <= 50 if variant == 0 else b1 < 50
+            if ok and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+                claimed[bi] = True
+                if variant == 0:
+                    match[bi] = ia
+                else:
+                    match[ia] = bi
+                if check_ori:
+                    rot = np.float32(A.angle[ia]) - np.float32(angB[bi])
+                    if rot < 0:
+                        rot = np.float32(rot + np.float32(360.0))
+                    b = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + 0.5))
+                    hist[0 if b == 30 else b].append(bi if variant == 0 else int(ia))
+                nm += 1
+    return nm, match, hist
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_oracle_bow_against_numpy_restatement(orc, variant):
+    rng = np.random.default_rng(42 + variant)
+    lm = synth.random_descriptors(rng, 60)
+    mk = lambda: synth.make_frame(rng, lm, rng.integers(0, 60, 150), p_flip=0.05, n_nodes=8,
+                                  mp_flags=np.where(rng.random(150) < 0.85, MP_PRESENT | MP_OBS, 0).astype(np.uint8))
+    A, B = mk(), mk()
+    nm, match, hist = _numpy_search_bow(variant, A, B, 0.9, False)
+    cnt, m, ncmp = orc.search_bow(variant, A, B, 0.9, False)
+    assert cnt == nm and np.array_equal(m, match) and nm > 10
+    # with the rotation filter: apply ComputeThreeMaxima by hand to the numpy histogram
+    nm, match, hist = _numpy_search_bow(variant, A, B, 0.9, True)
+    keep = orc.three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in keep:
+            for v in hist[b]:
+                match[v] = -1
+                nm -= 1
+    cnt, m, _ = orc.search_bow(variant, A, B, 0.9, True)
+    assert cnt == nm and np.array_equal(m, match)
+
+
+def test_oracle_proj_claims_known_answer(orc):
+    """Two map points project onto the same keypoint: the first (with observations) claims it, the second
+    must skip it (ORBmatcher.cc:113-115) and take the other keypoint in its window."""
+    d0, d1 = _desc(range(30)), _desc(range(100, 130))
+    f = FrameData(desc=np.array([d0, d1]), x=[100.0, 101.0], y=[100.0, 100.0], angle=np.zeros(2), octave=np.zeros(2, np.int32))
+    q = ProjQueries(desc=np.array([d0, d0]), proj_x=[100.0, 100.0], proj_y=[100.0, 100.0], proj_xr=[-1.0, -1.0],
+                    level=np.zeros(2, np.int32), view_cos=[0.95, 0.95], flags=np.array([Q_VALID | Q_OBS, Q_VALID | Q_OBS], np.uint8))
+    cnt, owner, ncmp = orc.search_proj_points(f, q, 1.0, 0.8)
+    # query 0: best d=0 (kp0), second = 60 (kp1), same level: 0 > 0.8*60 false -> accept kp0.
+    # query 1: kp0 skipped; only kp1 at distance 60 <= 100, bestLevel2 = -1 != 0 -> accept kp1.
+    assert cnt == 2 and list(owner) == [0, 1] and ncmp == 3
+    # if query 0 has no observations, query 1 may overwrite slot 0 (and the count is still 2)
+    q.flags[:] = [Q_VALID, Q_VALID | Q_OBS]
+    cnt, owner, ncmp = orc.search_proj_points(f, q, 1.0, 0.8)
+    assert cnt == 2 and list(owner) == [1, -1] and ncmp == 4
+
+
+def test_predict_scale_known_answers(orc):
+    lsf = float(np.log(np.float32(1.2)))
+    assert orc.predict_scale(10.0, 10.0, lsf, 8) == 0
+    assert orc.predict_scale(10.0, 100.0, lsf, 8) == 0          # negative -> clamped to 0
+    assert orc.predict_scale(10.0, 10.0 / 1.2 ** 2.5, lsf, 8) == 3
+    assert orc.predict_scale(10.0, 0.001, lsf, 8) == 7          # clamped to levels-1
