@@ -1,0 +1,34 @@
+"""Turns gpurun_out/prof_<tag>/ (scripts/profile_bench.sh) into committed summaries under profiles/."""
+import csv, glob, json, os, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+ks = glob.glob(f"{src}/kt/*/*_kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(ks)))
+with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
+    w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+def counters(sub):
+    f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "bf2nn" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+fetch, nf = counters("fetch"); write, _ = counters("write"); sq, _ = counters("sq")
+bf = [r for r in rows if "bf2nn" in r["Name"]][0]
+P, N = 4096, 2000
+alg_bytes = P * (2 * N * 32 + N * 4 + 4)      # both descriptor sets once per pair + match row + count
+# MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
+# 16-byte-per-lane coalesced reads (our staging and query loads) -> doubled
+hbm = (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024
+summ = {"tag": tag, "kernel": bf["Name"][:80], "launches_profiled": int(bf["Calls"]), "avg_kernel_ns": float(bf["AverageNs"]),
+        "cmps_per_launch": P * N * N, "achieved_Tcmps": P * N * N / float(bf["AverageNs"]) / 1e3,
+        "FETCH_SIZE_KiB_raw": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": write["WRITE_SIZE"],
+        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg_bytes, "sq": sq,
+        "valu_insts_per_wave_cmp": sq.get("SQ_INSTS_VALU", 0) / (P * 2048 / 64 * N) if sq else None,
+        "clock_ghz_est": sq.get("GRBM_GUI_ACTIVE", 0) / 8 / float(bf["AverageNs"]) if sq else None}
+json.dump({"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_summary.json"}, open(f"profiles/{tag}_bf2nn_traffic.json", "w"))
+json.dump(summ, open(f"profiles/{tag}_bench_summary.json", "w"), indent=1)
+print(json.dumps(summ, indent=1))
