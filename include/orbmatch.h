@@ -191,7 +191,8 @@ int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *fram
  *          KeyFrame.cc:766-812) then octave in [min_level,max_level], slot skipped iff PRESENT,
  *          accept best <= dist_th (TH_LOW), no histogram.
  * slot_flags: as for orbm_search_proj_points_batch (CurrentFrame.mvpMapPoints / vpMatched).
- * owner[k*stride + idx] = query index written to the slot and surviving the rotation filter, else -1. */
+ * owner[k*stride + idx] = query index whose map point ends up in the slot; -1 = the call never wrote the
+ * slot; -2 = the slot was written and then set to NULL by the rotation filter (:1942, :2115). */
 int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame,
                              const int32_t *qset, int dist_th, int check_ori,
                              const uint8_t *slot_flags, int32_t stride, int32_t *owner,

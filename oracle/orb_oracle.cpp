@@ -493,7 +493,7 @@ int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries
         hist.maxima(ind1, ind2, ind3);
         for (int b = 0; b < HISTO_LENGTH; b++) {
             if (b != ind1 && b != ind2 && b != ind3)
-                for (int s : hist.bins[b]) { owner[s] = -1; nmatches--; }
+                for (int s : hist.bins[b]) { owner[s] = -2; nmatches--; }  // -2: written, then set to NULL
         }
     }
     if (ncmp) *ncmp = cnt.n;
@@ -560,10 +560,11 @@ int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float 
     return nmatches;
 }
 
-// MapPoint.cc:569-602 (PredictScale) in flat form: host-side helper of the a11 gates
+// MapPoint.cc:569-602 (PredictScale) in flat form: host-side helper of the a11 gates.  MapPoint.cc sees
+// `using namespace std` through the DBoW2 headers, so log(float)/ceil(float) resolve to the float overloads.
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels) {
     float ratio = max_distance / current_dist;
-    int nScale = (int)ceil(log(ratio) / log_scale_factor);
+    int nScale = (int)ceilf(logf(ratio) / log_scale_factor);
     if (nScale < 0) nScale = 0;
     else if (nScale >= n_levels) nScale = n_levels - 1;
     return nScale;

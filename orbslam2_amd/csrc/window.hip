@@ -292,7 +292,7 @@ __global__ void window_kernel(WinParams P) {
             if (removed) atomicSub(nmatch, removed);
         } else {
             for (int i = tid; i < n; i += nthr)
-                if (binmask[i] & ~keepmask) owner[i] = -1;                                 // slot set to NULL
+                if (binmask[i] & ~keepmask) owner[i] = -2;                                 // slot set to NULL (:1942 / :2115)
         }
         __syncthreads();
     }

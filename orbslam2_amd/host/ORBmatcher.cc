@@ -1,0 +1,433 @@
+// ORBmatcher.cc -- host side of the drop-in ORB_SLAM2::ORBmatcher: flatten -> C ABI (HIP kernels) -> re-apply
+// the pointer side effects.  No matching arithmetic happens here; if liborbmatch_hip.so cannot create a
+// context the methods throw (there is no CPU fallback).
+#include "ORBmatcher.h"
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/orbmatch.h"
+#include "host_gates.h"
+
+using namespace std;
+
+namespace ORB_SLAM2 {
+
+const int ORBmatcher::TH_HIGH = 100;      // ORBmatcher.cc:37
+const int ORBmatcher::TH_LOW = 50;        // ORBmatcher.cc:38
+const int ORBmatcher::HISTO_LENGTH = 30;  // ORBmatcher.cc:39
+
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy;
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+
+namespace {
+
+// ---- one C-ABI context per calling thread (the reference calls the matcher from three threads) -------------
+int g_device = -1;
+struct ThreadCtx {
+    orbm_ctx *ctx = nullptr;
+    ~ThreadCtx() { if (ctx) orbm_destroy(ctx); }
+};
+orbm_ctx *Ctx() {
+    static thread_local ThreadCtx t;
+    if (!t.ctx) {
+        int dev = g_device;
+        if (dev < 0) { const char *e = getenv("ORBMATCH_DEVICE"); dev = e ? atoi(e) : 0; }
+        t.ctx = orbm_create(dev);
+        if (!t.ctx) throw runtime_error(string("ORBmatcher: cannot create a GPU context: ") + orbm_last_error(nullptr));
+    }
+    return t.ctx;
+}
+void Check(int rc, const char *what) {
+    if (rc < 0) throw runtime_error(string("ORBmatcher: ") + what + " failed: " + orbm_last_error(Ctx()));
+}
+
+// ---- flat snapshots -----------------------------------------------------------------------------------------
+struct Flat {
+    vector<float> x, y, angle, angle_raw;
+    vector<int32_t> octave;
+    vector<uint8_t> flags;
+    vector<uint32_t> fv_node, fv_off, fv_idx;
+    orbm_frame_view v;
+};
+
+uint8_t MpFlags(MapPoint *p) {
+    if (!p) return 0;
+    uint8_t f = ORBM_MP_PRESENT;
+    if (p->isBad()) f |= ORBM_MP_BAD;
+    if (p->Observations() > 0) f |= ORBM_MP_OBS;
+    return f;
+}
+
+template <class FrameLike>
+void FlattenCommon(Flat &o, const FrameLike &F, const vector<MapPoint *> &mps, bool with_fv) {
+    const int n = F.N;
+    o.x.resize(n); o.y.resize(n); o.angle.resize(n); o.angle_raw.resize(n); o.octave.resize(n); o.flags.assign(n, 0);
+    for (int i = 0; i < n; i++) {
+        o.x[i] = F.mvKeysUn[i].pt.x; o.y[i] = F.mvKeysUn[i].pt.y;
+        o.angle[i] = F.mvKeysUn[i].angle; o.angle_raw[i] = F.mvKeys.empty() ? F.mvKeysUn[i].angle : F.mvKeys[i].angle;
+        o.octave[i] = F.mvKeysUn[i].octave;
+        if (i < (int)mps.size()) o.flags[i] = MpFlags(mps[i]);
+    }
+    o.fv_off.assign(1, 0);
+    if (with_fv)
+        for (const auto &kv : F.mFeatVec) {   // ordered map: ascending node id, indices in stored order
+            o.fv_node.push_back(kv.first);
+            for (unsigned idx : kv.second) o.fv_idx.push_back(idx);
+            o.fv_off.push_back((uint32_t)o.fv_idx.size());
+        }
+    memset(&o.v, 0, sizeof o.v);
+    o.v.n = n;
+    o.v.desc = n ? F.mDescriptors.template ptr<uint8_t>() : nullptr;
+    o.v.x = o.x.data(); o.v.y = o.y.data(); o.v.angle = o.angle.data(); o.v.angle_raw = o.angle_raw.data();
+    o.v.octave = o.octave.data();
+    o.v.uright = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
+    o.v.mp_flags = o.flags.data();
+    o.v.n_levels = F.mnScaleLevels;
+    o.v.scale_factors = F.mvScaleFactors.data(); o.v.level_sigma2 = F.mvLevelSigma2.data();
+    o.v.n_nodes = (int)o.fv_node.size();
+    o.v.fv_node = o.fv_node.data(); o.v.fv_off = o.fv_off.data(); o.v.fv_idx = o.fv_idx.data();
+}
+
+void Flatten(Flat &o, const Frame &F, bool with_fv = false) {
+    FlattenCommon(o, F, F.mvpMapPoints, with_fv);
+    o.v.min_x = Frame::mnMinX; o.v.min_y = Frame::mnMinY; o.v.max_x = Frame::mnMaxX; o.v.max_y = Frame::mnMaxY;
+    o.v.inv_w = Frame::mfGridElementWidthInv; o.v.inv_h = Frame::mfGridElementHeightInv;
+}
+
+void Flatten(Flat &o, KeyFrame *pKF, bool with_fv = false) {
+    FlattenCommon(o, *pKF, pKF->GetMapPointMatches(), with_fv);
+    o.v.min_x = (float)pKF->mnMinX; o.v.min_y = (float)pKF->mnMinY; o.v.max_x = (float)pKF->mnMaxX; o.v.max_y = (float)pKF->mnMaxY;
+    o.v.inv_w = pKF->mfGridElementWidthInv; o.v.inv_h = pKF->mfGridElementHeightInv;
+}
+
+// transient device residency for one call
+struct Uploaded {
+    vector<int32_t> ids;
+    Uploaded(std::initializer_list<const orbm_frame_view *> views) {
+        vector<orbm_frame_view> v;
+        for (auto p : views) v.push_back(*p);
+        ids.resize(v.size());
+        Check(orbm_frames_upload(Ctx(), (int)v.size(), v.data(), ids.data()), "orbm_frames_upload");
+    }
+    ~Uploaded() { orbm_frames_free(Ctx(), (int)ids.size(), ids.data()); }
+};
+
+struct WinQ {
+    vector<uint8_t> desc, flags;
+    vector<float> u, v, radius, ur, angle;
+    vector<int32_t> minL, maxL;
+    explicit WinQ(int n) : desc((size_t)n * 32, 0), flags(n, 0), u(n, 0), v(n, 0), radius(n, 0), ur(n, 0), angle(n, 0), minL(n, 0), maxL(n, 0) {}
+    void SetDesc(int i, const cv::Mat &d) { memcpy(&desc[(size_t)i * 32], d.ptr<uint8_t>(), 32); }
+    // runs orbm_search_window_batch for one instance; returns nmatches, owner[] sized n_slots
+    int Run(int mode, int32_t frame_id, int n_slots, int dist_th, bool check_ori, bool with_ur, bool with_angle,
+            const uint8_t *slot_flags, vector<int32_t> &owner) {
+        orbm_win_queries q;
+        memset(&q, 0, sizeof q);
+        q.n = (int)flags.size();
+        q.desc = desc.data(); q.u = u.data(); q.v = v.data(); q.radius = radius.data();
+        q.min_level = minL.data(); q.max_level = maxL.data();
+        q.ur = with_ur ? ur.data() : nullptr; q.angle = with_angle ? angle.data() : nullptr; q.flags = flags.data();
+        int32_t qid = -1, count = 0;
+        Check(orbm_win_queries_upload(Ctx(), 1, &q, &qid), "orbm_win_queries_upload");
+        owner.assign(max(n_slots, 1), -1);
+        int rc = orbm_search_window_batch(Ctx(), mode, 1, &frame_id, &qid, dist_th, check_ori ? 1 : 0, slot_flags, n_slots,
+                                          owner.data(), &count, 0);
+        orbm_queries_free(Ctx(), 1, &qid);
+        Check(rc, "orbm_search_window_batch");
+        return count;
+    }
+};
+
+}  // namespace
+
+void ORBmatcher::SetDevice(int device) { g_device = device; }
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) {
+    const uint64_t *pa = a.ptr<uint64_t>(), *pb = b.ptr<uint64_t>();
+    return __builtin_popcountll(pa[0] ^ pb[0]) + __builtin_popcountll(pa[1] ^ pb[1]) +
+           __builtin_popcountll(pa[2] ^ pb[2]) + __builtin_popcountll(pa[3] ^ pb[3]);
+}
+
+// ---- ORBmatcher.cc:57-166 ---------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoints, const float th) {
+    const int Q = (int)vpMapPoints.size();
+    if (Q == 0 || F.N == 0) return 0;
+    vector<uint8_t> desc((size_t)Q * 32, 0), flags(Q, 0);
+    vector<float> px(Q, 0), py(Q, 0), pxr(Q, 0), vc(Q, 0);
+    vector<int32_t> lvl(Q, 0);
+    for (int i = 0; i < Q; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP->mbTrackInView) continue;       // :69
+        if (pMP->isBad()) continue;              // :72
+        flags[i] = ORBM_Q_VALID | (pMP->Observations() > 0 ? ORBM_Q_OBS : 0);
+        px[i] = pMP->mTrackProjX; py[i] = pMP->mTrackProjY; pxr[i] = pMP->mTrackProjXR;
+        lvl[i] = pMP->mnTrackScaleLevel; vc[i] = pMP->mTrackViewCos;
+        memcpy(&desc[(size_t)i * 32], pMP->GetDescriptor().ptr<uint8_t>(), 32);
+    }
+    Flat f;
+    Flatten(f, F);
+    Uploaded up({&f.v});
+    orbm_proj_queries q;
+    q.n = Q; q.desc = desc.data(); q.proj_x = px.data(); q.proj_y = py.data(); q.proj_xr = pxr.data();
+    q.level = lvl.data(); q.view_cos = vc.data(); q.flags = flags.data();
+    int32_t qid = -1, count = 0;
+    Check(orbm_proj_queries_upload(Ctx(), 1, &q, &qid), "orbm_proj_queries_upload");
+    vector<int32_t> owner(F.N, -1);
+    int rc = orbm_search_proj_points_batch(Ctx(), 1, up.ids.data(), &qid, th, mfNNratio, nullptr, F.N, owner.data(), &count, 0);
+    orbm_queries_free(Ctx(), 1, &qid);
+    Check(rc, "orbm_search_proj_points_batch");
+    for (int idx = 0; idx < F.N; idx++)
+        if (owner[idx] >= 0) F.mvpMapPoints[idx] = vpMapPoints[owner[idx]];   // :160
+    return count;
+}
+
+// ---- ORBmatcher.cc:218-385 ----------------------------------------------------------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPointMatches) {
+    const vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));   // :225
+    if (F.N == 0 || pKF->N == 0) return 0;
+    Flat a, b;
+    Flatten(a, pKF, true);
+    Flatten(b, F, true);
+    Uploaded up({&a.v, &b.v});
+    vector<int32_t> match(F.N, -1);
+    int32_t count = 0;
+    Check(orbm_search_bow_batch(Ctx(), 0, 1, &up.ids[0], &up.ids[1], mfNNratio, mbCheckOrientation ? 1 : 0, F.N, match.data(), &count, 0),
+          "orbm_search_bow_batch");
+    for (int i = 0; i < F.N; i++)
+        if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];          // :312
+    return count;
+}
+
+// ---- ORBmatcher.cc:703-854 ----------------------------------------------------------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12) {
+    const vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));   // :715
+    if (pKF1->N == 0 || pKF2->N == 0) return 0;
+    Flat a, b;
+    Flatten(a, pKF1, true);
+    Flatten(b, pKF2, true);
+    Uploaded up({&a.v, &b.v});
+    vector<int32_t> match(pKF1->N, -1);
+    int32_t count = 0;
+    Check(orbm_search_bow_batch(Ctx(), 1, 1, &up.ids[0], &up.ids[1], mfNNratio, mbCheckOrientation ? 1 : 0, pKF1->N, match.data(), &count, 0),
+          "orbm_search_bow_batch");
+    for (int i = 0; i < pKF1->N; i++)
+        if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];                  // :798
+    return count;
+}
+
+// ---- ORBmatcher.cc:562-689 ----------------------------------------------------------------------------------------
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize) {
+    const int n1 = (int)F1.mvKeysUn.size();
+    vnMatches12 = vector<int>(n1, -1);            // :566
+    if (n1 == 0 || F2.N == 0) return 0;
+    Flat a, b;
+    Flatten(a, F1);
+    Flatten(b, F2);
+    Uploaded up({&a.v, &b.v});
+    vector<float> prev((size_t)n1 * 2);
+    for (int i = 0; i < n1; i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+    vector<int32_t> m12(n1, -1);
+    int n = orbm_search_init(Ctx(), up.ids[0], up.ids[1], prev.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data());
+    Check(n, "orbm_search_init");
+    for (int i = 0; i < n1; i++) {
+        vnMatches12[i] = m12[i];
+        vbPrevMatched[i] = cv::Point2f(prev[2 * i], prev[2 * i + 1]);   // :684-686 (unchanged where unmatched)
+    }
+    return n;
+}
+
+// ---- ORBmatcher.cc:868-1093 ---------------------------------------------------------------------------------------
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo) {
+    // epipole of camera 1 in image 2 (:876-884)
+    cv::Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    float C2[3];
+    orbm_host::gemm3(R2w.ptr<float>(), 3, false, Cw.ptr<float>(), 1.0, t2w.ptr<float>(), C2);
+    const float invz = 1.0f / C2[2];
+    const float epi[2] = {pKF2->fx * C2[0] * invz + pKF2->cx, pKF2->fy * C2[1] * invz + pKF2->cy};
+    vMatchedPairs.clear();
+    if (pKF1->N == 0 || pKF2->N == 0) return 0;
+    Flat a, b;
+    Flatten(a, pKF1, true);
+    Flatten(b, pKF2, true);
+    Uploaded up({&a.v, &b.v});
+    float f12[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) f12[3 * r + c] = F12.at<float>(r, c);
+    vector<int32_t> m12(pKF1->N, -1);
+    int32_t count = 0;
+    Check(orbm_search_triang_batch(Ctx(), 1, &up.ids[0], &up.ids[1], f12, epi, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                   pKF1->N, m12.data(), &count, 0), "orbm_search_triang_batch");
+    vMatchedPairs.reserve(count);
+    for (size_t i = 0; i < m12.size(); i++)                                           // :1085-1090
+        if (m12[i] >= 0) vMatchedPairs.push_back(make_pair(i, (size_t)m12[i]));
+    return count;
+}
+
+// ---- ORBmatcher.cc:1768-1950 --------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) {
+    if (CurrentFrame.N == 0 || LastFrame.N == 0) return 0;
+    const float *Tcw = CurrentFrame.mTcw.ptr<float>();   // 4x4 row-major
+    const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+    float twc[3];
+    orbm_host::gemm3(Tcw, 4, true, tcw, -1.0, nullptr, twc);                           // :1783
+    const float *Tlw = LastFrame.mTcw.ptr<float>();
+    const float tlw[3] = {Tlw[3], Tlw[7], Tlw[11]};
+    float tlc[3];
+    orbm_host::gemm3(Tlw, 4, false, twc, 1.0, tlw, tlc);                               // :1791
+    const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;                          // :1795
+    const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;                        // :1796
+
+    WinQ q(LastFrame.N);
+    for (int i = 0; i < LastFrame.N; i++) {
+        MapPoint *pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        float x3Dc[3];
+        orbm_host::gemm3(Tcw, 4, false, x3Dw.ptr<float>(), 1.0, tcw, x3Dc);            // :1813
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        if (invzc < 0) continue;
+        float u = Frame::fx * xc * invzc + Frame::cx;
+        float v = Frame::fy * yc * invzc + Frame::cy;
+        if (u < Frame::mnMinX || u > Frame::mnMaxX) continue;
+        if (v < Frame::mnMinY || v > Frame::mnMaxY) continue;
+        const int nLastOctave = LastFrame.mvKeys[i].octave;
+        q.radius[i] = th * CurrentFrame.mvScaleFactors[nLastOctave];                   // :1845
+        if (bForward) { q.minL[i] = nLastOctave; q.maxL[i] = -1; }                     // :1859-1864
+        else if (bBackward) { q.minL[i] = 0; q.maxL[i] = nLastOctave; }
+        else { q.minL[i] = nLastOctave - 1; q.maxL[i] = nLastOctave + 1; }
+        q.u[i] = u; q.v[i] = v;
+        q.ur[i] = u - CurrentFrame.mbf * invzc;                                        // :1887
+        q.angle[i] = LastFrame.mvKeysUn[i].angle;
+        q.flags[i] = ORBM_Q_VALID | (pMP->Observations() > 0 ? ORBM_Q_OBS : 0);
+        q.SetDesc(i, pMP->GetDescriptor());
+    }
+    Flat f;
+    Flatten(f, CurrentFrame);
+    Uploaded up({&f.v});
+    vector<int32_t> owner;
+    const int n = q.Run(0, up.ids[0], CurrentFrame.N, TH_HIGH, mbCheckOrientation, true, true, nullptr, owner);
+    for (int idx = 0; idx < CurrentFrame.N; idx++) {
+        if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = LastFrame.mvpMapPoints[owner[idx]];   // :1906
+        else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = static_cast<MapPoint *>(NULL);  // :1942
+    }
+    return n;
+}
+
+// ---- ORBmatcher.cc:1963-2123 --------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist) {
+    if (CurrentFrame.N == 0) return 0;
+    const float *Tcw = CurrentFrame.mTcw.ptr<float>();
+    const float tcw[3] = {Tcw[3], Tcw[7], Tcw[11]};
+    float Ow[3];
+    orbm_host::gemm3(Tcw, 4, true, tcw, -1.0, nullptr, Ow);                            // :1969
+    const vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    WinQ q((int)vpMPs.size());
+    for (size_t i = 0; i < vpMPs.size(); i++) {
+        MapPoint *pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        float x3Dc[3];
+        orbm_host::gemm3(Tcw, 4, false, x3Dw.ptr<float>(), 1.0, tcw, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        const float u = Frame::fx * xc * invzc + Frame::cx;
+        const float v = Frame::fy * yc * invzc + Frame::cy;
+        if (u < Frame::mnMinX || u > Frame::mnMaxX) continue;
+        if (v < Frame::mnMinY || v > Frame::mnMaxY) continue;
+        const float *pw = x3Dw.ptr<float>();
+        const float PO[3] = {pw[0] - Ow[0], pw[1] - Ow[1], pw[2] - Ow[2]};
+        float dist3D = orbm_host::norm3(PO);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        q.radius[i] = th * CurrentFrame.mvScaleFactors[nPredictedLevel];                // :2026
+        q.minL[i] = nPredictedLevel - 1; q.maxL[i] = nPredictedLevel + 1;               // :2030
+        q.u[i] = u; q.v[i] = v;
+        q.angle[i] = pKF->mvKeysUn[i].angle;
+        q.flags[i] = ORBM_Q_VALID | ORBM_Q_OBS;
+        q.SetDesc((int)i, pMP->GetDescriptor());
+    }
+    Flat f;
+    Flatten(f, CurrentFrame);
+    Uploaded up({&f.v});
+    vector<int32_t> owner;
+    const int n = q.Run(1, up.ids[0], CurrentFrame.N, ORBdist, mbCheckOrientation, false, true, nullptr, owner);
+    for (int idx = 0; idx < CurrentFrame.N; idx++) {
+        if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = vpMPs[owner[idx]];        // :2066
+        else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = NULL;               // :2115
+    }
+    return n;
+}
+
+// ---- ORBmatcher.cc:401-542 ----------------------------------------------------------------------------------------
+int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, vector<MapPoint *> &vpMatched, int th) {
+    if (pKF->N == 0 || vpPoints.empty()) return 0;
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    // decompose Scw (:411-415): sRcw / scw with the scalar applied as a double reciprocal, as cv::Mat does
+    const float *S = Scw.ptr<float>();
+    const float row0[3] = {S[0], S[1], S[2]};
+    const float scw = sqrt(orbm_host::dot3(row0, row0));
+    const double inv = 1.0 / (double)scw;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Rcw[3 * r + c] = (float)((double)S[4 * r + c] * inv);
+        tcw[r] = (float)((double)S[4 * r + 3] * inv);
+    }
+    orbm_host::gemm3(Rcw, 3, true, tcw, -1.0, nullptr, Ow);
+    set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+
+    const int Q = (int)vpPoints.size();
+    WinQ q(Q);
+    for (int iMP = 0; iMP < Q; iMP++) {
+        MapPoint *pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        float p3Dc[3];
+        orbm_host::gemm3(Rcw, 3, false, p3Dw.ptr<float>(), 1.0, tcw, p3Dc);
+        if (p3Dc[2] < 0.0) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const float *pw = p3Dw.ptr<float>();
+        const float PO[3] = {pw[0] - Ow[0], pw[1] - Ow[1], pw[2] - Ow[2]};
+        const float dist = orbm_host::norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (orbm_host::dot3(PO, Pn.ptr<float>()) < 0.5 * dist) continue;                  // :487
+        const int nPredictedLevel = pMP->PredictScale(dist, pKF);
+        q.radius[iMP] = th * pKF->mvScaleFactors[nPredictedLevel];                        // :495
+        q.minL[iMP] = nPredictedLevel - 1; q.maxL[iMP] = nPredictedLevel;                 // :517
+        q.u[iMP] = u; q.v[iMP] = v;
+        q.flags[iMP] = ORBM_Q_VALID | ORBM_Q_OBS;
+        q.SetDesc(iMP, pMP->GetDescriptor());
+    }
+    Flat f;
+    Flatten(f, pKF);
+    Uploaded up({&f.v});
+    vector<uint8_t> slot(pKF->N, 0);
+    for (int i = 0; i < pKF->N && i < (int)vpMatched.size(); i++) slot[i] = vpMatched[i] ? ORBM_MP_PRESENT : 0;   // :512
+    vector<int32_t> owner;
+    const int n = q.Run(2, up.ids[0], pKF->N, TH_LOW, false, false, false, slot.data(), owner);
+    for (int idx = 0; idx < pKF->N; idx++)
+        if (owner[idx] >= 0) vpMatched[idx] = vpPoints[owner[idx]];                       // :535
+    return n;
+}
+
+}  // namespace ORB_SLAM2

@@ -1,0 +1,66 @@
+// ORBmatcher.h -- drop-in for ORB_SLAM2::ORBmatcher (reference ORBmatcher.h:39-257) whose search methods run
+// on MI355X through the C ABI of include/orbmatch.h.  Same class name, namespace, constructor, method
+// signatures, public constants and return values as the reference; callers (Tracking.cc:768-1879,
+// LocalMapping.cc:416, LoopClosing.cc:417-659) compile unchanged.
+//
+// Each method snapshots the pointer graph into flat arrays (descriptors, keypoints, FeatureVector CSR, map
+// point flags), calls ONE batched entry point of liborbmatch_hip.so and re-applies the pointer side effects
+// the reference makes (F.mvpMapPoints[...] = pMP, vpMatched[...] = pMP, vbPrevMatched, ...).  The snapshot
+// equals what the reference reads because its callers hold Map::mMutexMapUpdate or work on local copies
+// ("Pointer graph <-> flat arrays").
+//
+// Not yet ported ("next"): SearchBySim3 and the two Fuse overloads.
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "orbslam_types.h"
+
+namespace ORB_SLAM2 {
+
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+
+    // Hamming distance of two 32-byte descriptors (ORBmatcher.cc:2184-2200).  A scalar host helper for the
+    // callers outside the matcher (Frame.cc:720, MapPoint.cc:418); the searches below never call it.
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+
+    // ORBmatcher.cc:57-166 (Tracking::SearchLocalPoints)
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3);
+    // ORBmatcher.cc:1768-1950 (Tracking::TrackWithMotionModel)
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+    // ORBmatcher.cc:1963-2123 (Tracking::Relocalization)
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
+    // ORBmatcher.cc:401-542 (LoopClosing::ComputeSim3)
+    int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
+
+    // ORBmatcher.cc:218-385 and 703-854
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
+
+    // ORBmatcher.cc:562-689
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10);
+
+    // ORBmatcher.cc:868-1093
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo);
+
+public:
+    static const int TH_LOW;
+    static const int TH_HIGH;
+    static const int HISTO_LENGTH;
+
+    // Extension (not in the reference): GPU the calling thread's searches run on; default 0 or $ORBMATCH_DEVICE.
+    static void SetDevice(int device);
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+}  // namespace ORB_SLAM2
+
+#endif  // ORBMATCHER_H
