@@ -1,0 +1,95 @@
+"""Generates tests/golden/*.npz: small seeded inputs plus the CPU ORACLE's outputs for them.
+
+The reference tree has no runnable matcher, tests or fixtures, so these are regression vectors
+of the oracle (parity unpinned), not reference outputs.  Re-run from the repo root:
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from orbslam2_amd import synth  # noqa: E402
+from orbslam2_amd.views import FrameData, ProjQueries, WinQueries  # noqa: E402
+from oracle import oracle_ffi as orc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+FRAME_KEYS = ["desc", "x", "y", "angle", "octave", "uright", "mp_flags", "fv_node", "fv_off", "fv_idx"]
+
+
+def pack_frame(prefix, f):
+    d = {}
+    for k in FRAME_KEYS:
+        v = getattr(f, k)
+        if v is not None:
+            d[f"{prefix}_{k}"] = v
+    return d
+
+
+def unpack_frame(z, prefix):
+    kw = {k: z[f"{prefix}_{k}"] for k in FRAME_KEYS if f"{prefix}_{k}" in z}
+    return FrameData(**kw)
+
+
+def pack_q(prefix, q, keys):
+    return {f"{prefix}_{k}": getattr(q, k) for k in keys if getattr(q, k) is not None}
+
+
+PQ_KEYS = ["desc", "proj_x", "proj_y", "proj_xr", "level", "view_cos", "flags"]
+WQ_KEYS = ["desc", "u", "v", "radius", "min_level", "max_level", "ur", "angle", "flags"]
+
+
+def main():
+    kfs = synth.keyframe_pool(seed=11, n_kf=2, n=300, window=450, mp_valid_frac=0.9, stereo_frac=0.3, bad_frac=0.05)
+    a, b = kfs
+    d = {}
+    d.update(pack_frame("a", a)); d.update(pack_frame("b", b))
+    c, m, bd, sd, _ = orc.bf2nn(a, b, 0.75, 50)
+    d.update(bf_count=c, bf_match=m, bf_best=bd, bf_second=sd)
+    for variant in (0, 1):
+        for ori in (0, 1):
+            c, m, _ = orc.search_bow(variant, a, b, 0.75, bool(ori))
+            d[f"bow{variant}{ori}_count"] = c; d[f"bow{variant}{ori}_match"] = m
+    np.savez_compressed(os.path.join(OUT, "pair_bf_bow.npz"), **d)
+
+    f1, f2, f12, ep = synth.triang_pair(12, n=400)
+    d = {}
+    d.update(pack_frame("a", f1)); d.update(pack_frame("b", f2)); d.update(f12=f12, epipole=ep)
+    for os_ in (0, 1):
+        for ori in (0, 1):
+            c, m, _ = orc.search_triang(f1, f2, f12, ep, bool(os_), bool(ori))
+            d[f"tri{os_}{ori}_count"] = c; d[f"tri{os_}{ori}_match"] = m
+    np.savez_compressed(os.path.join(OUT, "triang.npz"), **d)
+
+    f, q = synth.proj_instance(seed=13, n=300, n_queries=1500, stereo=True, claimed_frac=0.15, obs_frac=0.7, valid_frac=0.9)
+    d = {}
+    d.update(pack_frame("f", f)); d.update(pack_q("q", q, PQ_KEYS))
+    for th in (1.0, 3.0):
+        c, o, _ = orc.search_proj_points(f, q, th, 0.8)
+        d[f"proj{int(th)}_count"] = c; d[f"proj{int(th)}_owner"] = o
+    np.savez_compressed(os.path.join(OUT, "proj_points.npz"), **d)
+
+    d = {}
+    for mode, dist_th in ((0, 100), (1, 64), (2, 50)):
+        f, q = synth.window_instance(14 + mode, mode, n=300, n_queries=800, stereo=(mode == 0))
+        d.update(pack_frame(f"f{mode}", f)); d.update(pack_q(f"q{mode}", q, WQ_KEYS))
+        for ori in (0, 1):
+            c, o, _ = orc.search_window(mode, f, q, dist_th, bool(ori))
+            d[f"win{mode}{ori}_count"] = c; d[f"win{mode}{ori}_owner"] = o
+    np.savez_compressed(os.path.join(OUT, "window_modes.npz"), **d)
+
+    f1, f2, prev = synth.init_pair(seed=17, n=500)
+    d = {}
+    d.update(pack_frame("a", f1)); d.update(pack_frame("b", f2)); d["prev"] = prev
+    c, m, p, _ = orc.search_init(f1, f2, prev, 100, 0.9, True)
+    d.update(init_count=c, init_match=m, init_prev=p)
+    np.savez_compressed(os.path.join(OUT, "init.npz"), **d)
+    for fn in sorted(os.listdir(OUT)):
+        if fn.endswith(".npz"):
+            print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle):
+ - CPU: the oracle still reproduces them (regression of the checker);
+ - GPU: the HIP path reproduces them through the C ABI, bit for bit."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+mg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mg)
+from orbslam2_amd.views import ProjQueries, WinQueries  # noqa: E402
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name))
+
+
+def unpack_q(z, prefix, cls, keys):
+    return cls(**{k: z[f"{prefix}_{k}"] for k in keys if f"{prefix}_{k}" in z})
+
+
+class OracleSide:
+    def __init__(self, orc):
+        self.orc = orc
+
+    def bf(self, a, b): c, m, bd, sd, _ = self.orc.bf2nn(a, b, 0.75, 50); return c, m, bd, sd
+    def bow(self, v, a, b, ori): c, m, _ = self.orc.search_bow(v, a, b, 0.75, ori); return c, m
+    def tri(self, a, b, f12, ep, os_, ori): c, m, _ = self.orc.search_triang(a, b, f12, ep, os_, ori); return c, m
+    def proj(self, f, q, th): c, o, _ = self.orc.search_proj_points(f, q, th, 0.8); return c, o
+    def win(self, mode, f, q, dth, ori): c, o, _ = self.orc.search_window(mode, f, q, dth, ori); return c, o
+    def init(self, a, b, prev): c, m, p, _ = self.orc.search_init(a, b, prev, 100, 0.9, True); return c, m, p
+
+
+class GpuSide:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def _up(self, *frames):
+        return self.ctx.upload_frames(list(frames))
+
+    def bf(self, a, b):
+        ids = self._up(a, b); c, m, bd, sd = self.ctx.bf2nn([ids[0]], [ids[1]], 0.75, 50, stride=a.n); self.ctx.free_frames(ids)
+        return c[0], m[0], bd[0], sd[0]
+
+    def bow(self, v, a, b, ori):
+        ids = self._up(a, b); n = b.n if v == 0 else a.n
+        c, m = self.ctx.search_bow(v, [ids[0]], [ids[1]], 0.75, ori, stride=n); self.ctx.free_frames(ids)
+        return c[0], m[0]
+
+    def tri(self, a, b, f12, ep, os_, ori):
+        ids = self._up(a, b); c, m = self.ctx.search_triang([ids[0]], [ids[1]], f12[None], ep[None], os_, ori, stride=a.n)
+        self.ctx.free_frames(ids); return c[0], m[0]
+
+    def proj(self, f, q, th):
+        ids = self._up(f); qid = self.ctx.upload_proj_queries([q])
+        c, o = self.ctx.search_proj_points(ids, qid, th, 0.8, stride=f.n); self.ctx.free_frames(ids); self.ctx.free_queries(qid)
+        return c[0], o[0]
+
+    def win(self, mode, f, q, dth, ori):
+        ids = self._up(f); qid = self.ctx.upload_win_queries([q])
+        c, o = self.ctx.search_window(mode, ids, qid, dth, ori, stride=f.n); self.ctx.free_frames(ids); self.ctx.free_queries(qid)
+        return c[0], o[0]
+
+    def init(self, a, b, prev):
+        ids = self._up(a, b); r = self.ctx.search_init(ids[0], ids[1], prev, 100, 0.9, True); self.ctx.free_frames(ids)
+        return r
+
+
+def check_all(side):
+    z = load("pair_bf_bow.npz")
+    a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
+    c, m, bd, sd = side.bf(a, b)
+    assert c == z["bf_count"] and np.array_equal(m, z["bf_match"]) and np.array_equal(bd, z["bf_best"]) and np.array_equal(sd, z["bf_second"])
+    for v in (0, 1):
+        for ori in (0, 1):
+            c, m = side.bow(v, a, b, bool(ori))
+            assert c == z[f"bow{v}{ori}_count"] and np.array_equal(m, z[f"bow{v}{ori}_match"])
+    z = load("triang.npz")
+    a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
+    for os_ in (0, 1):
+        for ori in (0, 1):
+            c, m = side.tri(a, b, z["f12"], z["epipole"], bool(os_), bool(ori))
+            assert c == z[f"tri{os_}{ori}_count"] and np.array_equal(m, z[f"tri{os_}{ori}_match"])
+    z = load("proj_points.npz")
+    f, q = mg.unpack_frame(z, "f"), unpack_q(z, "q", ProjQueries, mg.PQ_KEYS)
+    for th in (1.0, 3.0):
+        c, o = side.proj(f, q, th)
+        assert c == z[f"proj{int(th)}_count"] and np.array_equal(o, z[f"proj{int(th)}_owner"])
+    z = load("window_modes.npz")
+    for mode, dth in ((0, 100), (1, 64), (2, 50)):
+        f, q = mg.unpack_frame(z, f"f{mode}"), unpack_q(z, f"q{mode}", WinQueries, mg.WQ_KEYS)
+        for ori in (0, 1):
+            c, o = side.win(mode, f, q, dth, bool(ori))
+            assert c == z[f"win{mode}{ori}_count"] and np.array_equal(o, z[f"win{mode}{ori}_owner"])
+    z = load("init.npz")
+    a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
+    c, m, p = side.init(a, b, z["prev"])
+    assert c == z["init_count"] and np.array_equal(m, z["init_match"]) and np.array_equal(p, z["init_prev"])
+
+
+def test_oracle_reproduces_golden(orc):
+    check_all(OracleSide(orc))
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_golden(ctx):
+    check_all(GpuSide(ctx))
