@@ -133,13 +133,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal only: ORBM_BENCH_BACKEND=gloo lets N ranks share one GPU (records hop through host memory)
+    backend = os.environ.get("ORBM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     kfs, ids = build_store(ctx, seed=20161013)           # same store on every rank (replicated, 6 MB)
     rng = np.random.default_rng(1000 + rank)              # every rank matches its own pairs
@@ -150,8 +156,10 @@ def main():
     counts = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2)]
     packed = [torch.empty((P, N_FEAT + 2), dtype=torch.int16, device=dev) for _ in range(2)]
     gather_bufs = None
+    rec_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1 and rank == 0:
-        gather_bufs = [[torch.empty_like(packed[0]) for _ in range(world)] for _ in range(2)]
+        # records travel as bytes: neither NCCL/RCCL nor gloo has an int16 datatype
+        gather_bufs = [[torch.empty(packed[0].view(torch.uint8).shape, dtype=torch.uint8, device=rec_dev) for _ in range(world)] for _ in range(2)]
     pending = [None, None]
     kern_ms = []
 
@@ -169,7 +177,10 @@ def main():
             # match list record per pair: 2000 x int16 candidate index (-1 = none) + the int32 count
             packed[b][:, :N_FEAT] = match[b]
             packed[b][:, N_FEAT:] = counts[b].view(torch.int16).view(P, 2)
-            pending[b] = dist.gather(packed[b], gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+            rec = packed[b].view(torch.uint8)
+            if backend != "nccl":
+                rec = rec.cpu()
+            pending[b] = dist.gather(rec, gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
         for b in (0, 1):
@@ -193,7 +204,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=rec_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
