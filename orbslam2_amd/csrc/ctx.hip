@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
             while (j > b && f.cell_idx[j - 1] > v) { f.cell_idx[j] = f.cell_idx[j - 1]; j--; }
             f.cell_idx[j] = v;
         }
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t k = f.cell_idx[i];
+            f.cell_rec[i] = make_float4(f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16)));
+        }
     }
 }
 
@@ -281,7 +285,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
     if (n_frames < 0 || (n_frames > 0 && (!views || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "frames_upload: null argument");
     if (n_frames == 0) return ORBM_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    struct Offs { size_t desc, x, y, angle, angle_raw, uright, octave, flags, cell_off, cell_idx, fv_node, fv_off, fv_idx; };
+    struct Offs { size_t desc, x, y, angle, angle_raw, uright, octave, flags, cell_off, cell_idx, cell_rec, fv_node, fv_off, fv_idx; };
     std::vector<Offs> offs(n_frames);
     Packer pk;
     for (int k = 0; k < n_frames; k++) {
@@ -317,6 +321,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         o.flags = pk.add(v.mp_flags, n);
         o.cell_off = pk.add(nullptr, (ORBM_GRID_CELLS + 1) * 4);
         o.cell_idx = pk.add(nullptr, (n ? n : 1) * 4);
+        o.cell_rec = pk.add(nullptr, (n ? n : 1) * 16);
         o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4);
         o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4);
         o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4);
@@ -346,6 +351,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         f.octave = (const uint8_t *)(b + o.octave);
         f.mp_flags = (uint8_t *)(b + o.flags);
         f.cell_off = (uint32_t *)(b + o.cell_off); f.cell_idx = (uint32_t *)(b + o.cell_idx);
+        f.cell_rec = (float4 *)(b + o.cell_rec);
         f.fv_node = (const uint32_t *)(b + o.fv_node); f.fv_off = (const uint32_t *)(b + o.fv_off);
         f.fv_idx = (const uint32_t *)(b + o.fv_idx);
         f.min_x = v.min_x; f.min_y = v.min_y; f.max_x = v.max_x; f.max_y = v.max_y;

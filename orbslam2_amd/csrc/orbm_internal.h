@@ -10,7 +10,8 @@
 // Device-resident layout of one Frame / KeyFrame (replaces Frame.h:235-291 / KeyFrame.h:232-282):
 //  desc      packed 32-byte rows, 256-byte aligned base, row i = keypoint i
 //  x,y,...   keypoint SoA
-//  cell_*    64x48 grid as CSR, cell = ix*48+iy, indices ascending inside a cell (Frame.cc:278-298)
+//  cell_*    64x48 grid as CSR, cell = ix*48+iy, indices ascending inside a cell (Frame.cc:278-298);
+//            cell_rec[j] repeats keypoint cell_idx[j]'s x, y, uright, index and octave in CSR order
 //  fv_*      DBoW2::FeatureVector as CSR (nodes ascending)
 struct FrameDev {
     int32_t n, n_nodes, n_levels, pad0;
@@ -19,6 +20,7 @@ struct FrameDev {
     const uint8_t *octave;
     uint8_t *mp_flags;
     uint32_t *cell_off, *cell_idx;
+    float4 *cell_rec;   // cell-ordered copy {x, y, uright, idx | octave << 16}: the window walk streams it
     const uint32_t *fv_node, *fv_off, *fv_idx;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     float sf[ORBM_MAX_LEVELS];

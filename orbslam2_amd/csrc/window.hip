@@ -46,10 +46,20 @@ struct WinParams {
     int dist_th, check_ori, stride, window;
 };
 
+// Read-only frame data the walk and the distance loop touch, either in global memory or staged in LDS.
+struct FrameAcc {
+    const uint32_t *cell_off;   // 3073
+    const float4 *rec;          // cell-ordered {x, y, uright, idx | oct << 16}
+    const uint4 *desc;          // 2 per keypoint
+    float min_x, min_y, inv_w, inv_h;
+};
+
 // Frame::GetFeaturesInArea (Frame.cc:434-498) / KeyFrame::GetFeaturesInArea (KeyFrame.cc:766-812):
-// calls body(k, octave) for every keypoint the reference would push, in the reference's order.
+// calls body(k, octave, uright) for every keypoint the reference would push, in the reference's order
+// (ix ascending, iy ascending, insertion order).  Cells (ix, minY..maxY) are consecutive in the CSR, so a
+// column of the window is ONE contiguous run of 16-byte records.
 template <bool KF_MODE, typename Body>
-__device__ __forceinline__ void walk_window(const FrameDev &f, float x, float y, float r, int minLevel, int maxLevel,
+__device__ __forceinline__ void walk_window(const FrameAcc &f, float x, float y, float r, int minLevel, int maxLevel,
                                             Body &&body) {
     const float xr = __fsub_rn(x, f.min_x), yr = __fsub_rn(y, f.min_y);
     const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), f.inv_w)));
@@ -62,35 +72,53 @@ __device__ __forceinline__ void walk_window(const FrameDev &f, float x, float y,
     if (nMaxCellY < 0) return;
     const bool bCheckLevels = !KF_MODE && ((minLevel > 0) || (maxLevel >= 0));
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-        // cells (ix, nMinCellY..nMaxCellY) are consecutive in the CSR: one contiguous index range
         const uint32_t b = f.cell_off[ix * ORBM_GRID_ROWS + nMinCellY];
         const uint32_t e = f.cell_off[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
         for (uint32_t j = b; j < e; j++) {
-            const int k = (int)f.cell_idx[j];
-            const int oct = f.octave[k];
+            const float4 rc = f.rec[j];
+            const uint32_t w = __float_as_uint(rc.w);
+            const int oct = (int)(w >> 16);
             if (bCheckLevels) {
                 if (oct < minLevel) continue;
                 if (maxLevel >= 0 && oct > maxLevel) continue;
             }
-            const float distx = __fsub_rn(f.x[k], x), disty = __fsub_rn(f.y[k], y);
-            if (fabsf(distx) < r && fabsf(disty) < r) body(k, oct);
+            const float distx = __fsub_rn(rc.x, x), disty = __fsub_rn(rc.y, y);
+            if (fabsf(distx) < r && fabsf(disty) < r) body((int)(w & 0xFFFFu), oct, rc.z);
         }
     }
 }
 
-template <int MODE>
+constexpr int WIN_CACHE = 16;  // candidates remembered per query (registers); wider windows fall back to re-walking
+
+template <int MODE, bool LDS_FRAME>
 __global__ void window_kernel(WinParams P) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameDev &F = P.frames[P.frame_ids[inst]];
     const int n = F.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    // LDS carve: state[n] (flags | vMatchedDistance), owner[n], post[2][n], binmask[n], hist[30], misc
-    uint32_t *state = lds;
-    int32_t *owner = (int32_t *)(lds + n);
-    uint32_t *post0 = lds + 2 * (size_t)n, *post1 = lds + 3 * (size_t)n;
-    uint32_t *binmask = lds + 4 * (size_t)n;
-    int *hist = (int *)(lds + 5 * (size_t)n);
+    // LDS carve.  LDS_FRAME: [cell_off 3076][rec 4n][desc 8n] then the slot state; else slot state only.
+    FrameAcc acc;
+    acc.min_x = F.min_x; acc.min_y = F.min_y; acc.inv_w = F.inv_w; acc.inv_h = F.inv_h;
+    uint32_t *base = lds;
+    if (LDS_FRAME) {
+        uint32_t *l_cell = lds;
+        float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);
+        uint4 *l_desc = reinterpret_cast<uint4 *>(lds + 3076 + 4 * (size_t)n);
+        for (int i = tid; i <= ORBM_GRID_CELLS; i += nthr) l_cell[i] = F.cell_off[i];
+        for (int i = tid; i < n; i += nthr) l_rec[i] = F.cell_rec[i];
+        const uint4 *gd = reinterpret_cast<const uint4 *>(F.desc);
+        for (int i = tid; i < 2 * n; i += nthr) l_desc[i] = gd[i];
+        acc.cell_off = l_cell; acc.rec = l_rec; acc.desc = l_desc;
+        base = lds + 3076 + 12 * (size_t)n;
+    } else {
+        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = reinterpret_cast<const uint4 *>(F.desc);
+    }
+    uint32_t *state = base;                       // ORBM_MP_* flags | vMatchedDistance
+    int32_t *owner = (int32_t *)(base + n);
+    uint32_t *post0 = base + 2 * (size_t)n, *post1 = base + 3 * (size_t)n;
+    uint32_t *binmask = base + 4 * (size_t)n;
+    int *hist = (int *)(base + 5 * (size_t)n);
     int *nmatch = hist + 32;
     int *keep = hist + 33;
 
@@ -119,53 +147,103 @@ __global__ void window_kernel(WinParams P) {
     const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
                           (MODE == MODE_INIT || QS->angle != nullptr);
     const bool bFactor = P.th != 1.0f;                                                     // :61
+    const bool stereo_gate = MODE == MODE_PROJ || (MODE == MODE_LAST && QS->f3 != nullptr);
+    const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
 
-    for (int base = 0; base < Q; base += nthr) {
-        const int qi = base + tid;
-        // ---- load this lane's query (HBM is read once per query) --------------------------------------
-        bool unresolved = false;
-        uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float x = 0, y = 0, r = 0, xr = 0, qangle = 0;
-        int minL = -1, maxL = -1;
-        uint32_t qflags = 0;
-        if (qi < Q) {
-            if (MODE == MODE_INIT) {
-                if (F1->octave[qi] == 0) {                                                // :582-584
-                    unresolved = true;
-                    x = P.prev_xy[2 * qi]; y = P.prev_xy[2 * qi + 1];
-                    r = (float)P.window; minL = 0; maxL = 0;                              // :587
-                    qangle = F1->angle[qi];
-                }
-            } else {
-                qflags = QS->flags[qi];
-                if (qflags & ORBM_Q_VALID) {
-                    unresolved = true;
-                    x = QS->f0[qi]; y = QS->f1[qi];
-                    if (MODE == MODE_PROJ) {
-                        const int lvl = QS->l0[qi];
-                        float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;          // :168-174
-                        if (bFactor) rv = __fmul_rn(rv, P.th);                           // :84-85
-                        r = __fmul_rn(rv, F.sf[lvl]);                                    // :89
-                        minL = lvl - 1; maxL = lvl;
-                        xr = QS->f2[qi];
-                    } else {
-                        r = QS->f2[qi]; minL = QS->l0[qi]; maxL = QS->l1[qi];
-                        if (QS->f3) xr = QS->f3[qi];
-                        if (QS->angle) qangle = QS->angle[qi];
-                    }
-                }
+    // one query per lane; the NEXT chunk's query is loaded while the current chunk is matched
+    struct Query {
+        uint4 d0, d1;
+        float x, y, r, xr, angle;
+        int minL, maxL;
+        uint32_t flags;
+        bool valid;
+    };
+    auto load_query = [&](int qi) {
+        Query q;
+        q.d0 = q.d1 = make_uint4(0, 0, 0, 0);
+        q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.flags = 0; q.valid = false;
+        if (qi >= Q) return q;
+        if (MODE == MODE_INIT) {
+            if (F1->octave[qi] == 0) {                                                    // :582-584
+                q.valid = true;
+                q.x = P.prev_xy[2 * qi]; q.y = P.prev_xy[2 * qi + 1];
+                q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
+                q.angle = F1->angle[qi];
             }
-            if (unresolved)
-            {
-                const uint32_t *dsrc = MODE == MODE_INIT ? F1->desc : QS->desc;
-                const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
-                const uint4 lo = p4[0], hi = p4[1];
-                qd[0] = lo.x; qd[1] = lo.y; qd[2] = lo.z; qd[3] = lo.w; qd[4] = hi.x; qd[5] = hi.y; qd[6] = hi.z; qd[7] = hi.w;
+        } else {
+            q.flags = QS->flags[qi];
+            if (q.flags & ORBM_Q_VALID) {
+                q.valid = true;
+                q.x = QS->f0[qi]; q.y = QS->f1[qi];
+                if (MODE == MODE_PROJ) {
+                    const int lvl = QS->l0[qi];
+                    float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
+                    if (bFactor) rv = __fmul_rn(rv, P.th);                               // :84-85
+                    q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
+                    q.minL = lvl - 1; q.maxL = lvl;
+                    q.xr = QS->f2[qi];
+                } else {
+                    q.r = QS->f2[qi]; q.minL = QS->l0[qi]; q.maxL = QS->l1[qi];
+                    if (QS->f3) q.xr = QS->f3[qi];
+                    if (QS->angle) q.angle = QS->angle[qi];
+                }
             }
         }
-        const bool stereo_gate = MODE == MODE_PROJ || (MODE == MODE_LAST && QS->f3 != nullptr);
-        const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
+        if (q.valid) {
+            const uint32_t *dsrc = MODE == MODE_INIT ? F1->desc : QS->desc;
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
+            q.d0 = p4[0]; q.d1 = p4[1];
+        }
+        return q;
+    };
+
+    Query nextq = load_query(tid);
+    for (int base_q = 0; base_q < Q; base_q += nthr) {
+        const int qi = base_q + tid;
+        const Query cur = nextq;
+        nextq = load_query(qi + nthr);
+        bool unresolved = cur.valid;
+        const uint32_t qd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
+        const float x = cur.x, y = cur.y, r = cur.r, xr = cur.xr, qangle = cur.angle;
+        const int minL = cur.minL, maxL = cur.maxL;
+        const uint32_t qflags = cur.flags;
+
+        // ---- collect: ONE window walk per query.  The static gates (level range, |dx|<r, |dy|<r, octave filter,
+        // stereo gate) and the Hamming distance do not depend on the slot state, so the candidates that pass are
+        // remembered as k | oct << 16 | dist << 20 and the rounds below never walk again.  More than WIN_CACHE
+        // candidates (wide windows): the rounds fall back to walking.
+        int ncand = 0;
+        uint32_t cc[WIN_CACHE];
+#pragma unroll
+        for (int i = 0; i < WIN_CACHE; i++) cc[i] = 0;
+        if (unresolved) {
+            auto collect = [&](int k, int oct, float ur) {
+                if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }          // :515-518
+                if (stereo_gate) {
+                    if (ur > 0) {
+                        const float er = fabsf(__fsub_rn(xr, ur));
+                        if (er > r) return;                                                // :117-122 / :1883-1891
+                    }
+                }
+                if (ncand < WIN_CACHE) {
+                    const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                    const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    const uint32_t v = (uint32_t)k | ((uint32_t)oct << 16) | (hamming256(qd, cd) << 20);
+#pragma unroll
+                    for (int i = 0; i < WIN_CACHE; i++) if (i == ncand) cc[i] = v;
+                }
+                ncand++;
+            };
+            if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, collect);
+            else walk_window<false>(acc, x, y, r, minL, maxL, collect);
+            if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
+        }
+        const bool cached = ncand <= WIN_CACHE;
+        int wave_ncand = min(ncand, WIN_CACHE);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
+        wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
 
         int round = 0;
         while (true) {
@@ -173,50 +251,66 @@ __global__ void window_kernel(WinParams P) {
             uint32_t *post_next = (round & 1) ? post0 : post1;
             int bestDist = MODE == MODE_INIT ? INT_MAX : 256, bestDist2 = bestDist, bestIdx = -1;
             int bestLevel = -1, bestLevel2 = -1;
+            // the reference's inner loop body for one candidate that passed the static gates
+            auto consider = [&](int k, int oct, int dist) {
+                const uint32_t st = state[k];
+                if (MODE == MODE_PROJ || MODE == MODE_LAST) {
+                    if ((st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS)) return;              // :113-115 / :1879-1881
+                } else if (MODE != MODE_INIT) {
+                    if (st & ORBM_MP_PRESENT) return;                                      // :2048 / :512
+                }
+                if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                    // :608
+                if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                       // this query may still claim k
+                if (dist < bestDist) {
+                    bestDist2 = bestDist; bestDist = dist;
+                    bestLevel2 = bestLevel; bestLevel = oct;
+                    bestIdx = k;
+                } else if (dist < bestDist2) {
+                    bestLevel2 = oct; bestDist2 = dist;
+                }
+            };
             // ---- evaluate ---------------------------------------------------------------------------
             if (unresolved) {
-                auto body = [&](int k, int oct) {
-                    if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }      // :515-518
-                    const uint32_t st = state[k];
-                    if (MODE == MODE_PROJ || MODE == MODE_LAST) {
-                        if ((st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS)) return;          // :113-115 / :1879-1881
-                    } else if (MODE != MODE_INIT) {
-                        if (st & ORBM_MP_PRESENT) return;                                  // :2048 / :512
+                if (cached) {
+                    // wave-uniform trip count: the register array is indexed by a scalar (v_movrels), no unrolling
+                    for (int i = 0; i < wave_ncand; i++) {
+                        const uint32_t v = cc[i];
+                        if (i < ncand) consider((int)(v & 0xFFFFu), (int)((v >> 16) & 15u), (int)(v >> 20));
                     }
-                    if (stereo_gate) {
-                        const float ur = F.uright[k];
-                        if (ur > 0) {
-                            const float er = fabsf(__fsub_rn(xr, ur));
-                            if (er > r) return;                                            // :117-122 / :1883-1891
+                } else {
+                    auto body = [&](int k, int oct, float ur) {
+                        if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
+                        if (stereo_gate) {
+                            if (ur > 0) {
+                                const float er = fabsf(__fsub_rn(xr, ur));
+                                if (er > r) return;
+                            }
                         }
-                    }
-                    const uint4 *p4 = reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)k;
-                    const uint4 lo = p4[0], hi = p4[1];
-                    const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const int dist = (int)hamming256(qd, cd);
-                    if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                // :608
-                    if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                   // this query may still claim k
-                    if (dist < bestDist) {
-                        bestDist2 = bestDist; bestDist = dist;
-                        bestLevel2 = bestLevel; bestLevel = oct;
-                        bestIdx = k;
-                    } else if (dist < bestDist2) {
-                        bestLevel2 = oct; bestDist2 = dist;
-                    }
-                };
-                if (MODE == MODE_SIM3) walk_window<true>(F, x, y, r, minL, maxL, body);
-                else walk_window<false>(F, x, y, r, minL, maxL, body);
+                        const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                        const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        consider(k, oct, (int)hamming256(qd, cd));
+                    };
+                    if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, body);
+                    else walk_window<false>(acc, x, y, r, minL, maxL, body);
+                }
             }
             __syncthreads();
             // ---- decide -----------------------------------------------------------------------------
             if (unresolved) {
                 bool is_final = true;
-                auto chk = [&](int k, int oct) {
-                    if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
-                    if (post[k] < (uint32_t)tid) is_final = false;
-                };
-                if (MODE == MODE_SIM3) walk_window<true>(F, x, y, r, minL, maxL, chk);
-                else walk_window<false>(F, x, y, r, minL, maxL, chk);
+                if (cached) {
+                    for (int i = 0; i < wave_ncand; i++) {
+                        const uint32_t v = cc[i];
+                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)tid) is_final = false;
+                    }
+                } else {
+                    auto chk = [&](int k, int oct, float) {
+                        if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
+                        if (post[k] < (uint32_t)tid) is_final = false;
+                    };
+                    if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, chk);
+                    else walk_window<false>(acc, x, y, r, minL, maxL, chk);
+                }
                 if (is_final) {
                     unresolved = false;
                     bool accept;
@@ -247,12 +341,12 @@ __global__ void window_kernel(WinParams P) {
                     }
                 }
             }
-            // reset the other post buffer for the next round (nobody reads it in this phase)
+            // the other post buffer is idle in this phase (decide only reads `post`): clear it for the next round
             for (int i = tid; i < n; i += nthr) post_next[i] = NOPOST;
             if (!__syncthreads_or(unresolved ? 1 : 0)) break;
             round++;
         }
-        // both post buffers must be clean for the next chunk: post (this round's) still holds entries
+        // leave both post buffers clean for the next chunk
         {
             uint32_t *post = (round & 1) ? post1 : post0;
             for (int i = tid; i < n; i += nthr) post[i] = NOPOST;
@@ -307,18 +401,27 @@ __global__ void window_kernel(WinParams P) {
     if (tid == 0) P.counts[inst] = *nmatch;
 }
 
-size_t win_lds_bytes(int n) { return ((size_t)5 * n + 64) * 4; }
+constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint <= 160 KB
+
+template <int MODE, bool LDS_FRAME>
+int launch_mode2(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
+    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64) * 4;
+    if (lds > 48 * 1024) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME>), dim3(n_inst), dim3(threads), lds, ctx->stream, P);
+    HIPCHK(ctx, hipGetLastError());
+    return ORBM_OK;
+}
+
+int g_win_force_global = 0;   // tuning / test knob: 1 = never stage the frame in LDS
 
 template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
-    const size_t lds = win_lds_bytes(max_n);
-    if (lds > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(window_kernel<MODE>, dim3(n_inst), dim3(threads), lds, ctx->stream, P);
-    HIPCHK(ctx, hipGetLastError());
-    return ORBM_OK;
+    // the whole frame (grid, records, descriptors) fits one CU's LDS up to 2200 keypoints: 1024-thread workgroup
+    if (max_n <= WIN_LDS_FRAME_MAX_N && !g_win_force_global) return launch_mode2<MODE, true>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024);
+    return launch_mode2<MODE, false>(ctx, P, n_inst, max_n, threads);
 }
 
 int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n) {
@@ -378,6 +481,9 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
 }
 
 }  // namespace
+
+// tuning / test knob (not part of the public ABI): 1 = keep the frame in global memory even when it fits LDS
+extern "C" void orbm__window_force_global(int v) { g_win_force_global = v; }
 
 extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
                                              float th, float ratio, const uint8_t *slot_flags, int32_t stride,

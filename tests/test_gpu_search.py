@@ -205,3 +205,35 @@ def test_search_init_steals(ctx, orc):
     wc, wm, wprev, _ = orc.search_init(f1, f2, prev, 150, 1.5, True)
     assert cnt == wc and np.array_equal(m12, wm) and np.array_equal(prev_out, wprev)
     ctx.free_frames(ids)
+
+
+def test_window_global_memory_path_still_exact(ctx, orc):
+    """Frames above 2200 keypoints (and the force-global knob) use the kernel variant that reads the frame from
+    global memory instead of LDS: same results."""
+    from orbslam2_amd import _lib
+    f, q = synth.proj_instance(seed=901, n=3000, n_queries=8000, claimed_frac=0.1, obs_frac=0.7)
+    fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+    counts, owner = ctx.search_proj_points(fid, qid, 3.0, 0.8, stride=3000)
+    wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8)
+    assert counts[0] == wc and np.array_equal(owner[0], wo)
+    ctx.free_frames(fid); ctx.free_queries(qid)
+    L = _lib.load()
+    try:
+        L.orbm__window_force_global(1)
+        f, q = synth.proj_instance(seed=902, n=800, n_queries=5000, stereo=True, obs_frac=0.6)
+        fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+        counts, owner = ctx.search_proj_points(fid, qid, 5.0, 0.8, stride=800)
+        wc, wo, _ = orc.search_proj_points(f, q, 5.0, 0.8)
+        assert counts[0] == wc and np.array_equal(owner[0], wo)
+        ctx.free_frames(fid); ctx.free_queries(qid)
+    finally:
+        L.orbm__window_force_global(0)
+
+
+def test_frames_over_the_window_limit_are_rejected(ctx):
+    from orbslam2_amd.matcher import OrbmError
+    f, q = synth.proj_instance(seed=903, n=9000, n_queries=10)
+    fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+    with pytest.raises(OrbmError):
+        ctx.search_proj_points(fid, qid, 3.0, 0.8, stride=9000)
+    ctx.free_frames(fid); ctx.free_queries(qid)
