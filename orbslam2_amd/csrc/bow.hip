@@ -121,20 +121,41 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
                 x2 = B.x[idxB0]; y2 = B.y[idxB0]; oct2 = B.octave[idxB0];
             }
         }
+        uint32_t lq[8];
+        int lq_idx = 0, lq_st = 0;
+        uint32_t lq_flags = 0;
+        float lq_x = 0.f, lq_y = 0.f;
         for (uint32_t qa = 0; qa < nA; qa++) {
-            const int idxA = (int)A.fv_idx[offA + qa];
-            const uint8_t fA = A.mp_flags[idxA];
+            // The node's queries are fetched 64 at a time, one per lane (index, flags, descriptor, position), and
+            // handed to the whole wave with v_readlane: the in-order loop then has no dependent global load.
+            if ((qa & 63u) == 0) {
+                const uint32_t ql = qa + lane;
+                lq_idx = 0; lq_flags = 0; lq_x = 0.f; lq_y = 0.f; lq_st = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) lq[i] = 0;
+                if (ql < nA) {
+                    lq_idx = (int)A.fv_idx[offA + ql];
+                    lq_flags = A.mp_flags[lq_idx];
+                    load_row(A.desc, lq_idx, lq);
+                    if (MODE == 2) { lq_x = A.x[lq_idx]; lq_y = A.y[lq_idx]; lq_st = A.uright[lq_idx] >= 0 ? 1 : 0; }
+                }
+            }
+            const int src = (int)(qa & 63u);
+            const int idxA = __builtin_amdgcn_readlane(lq_idx, src);
+            const uint32_t fA = (uint32_t)__builtin_amdgcn_readlane((int)lq_flags, src);
             bool st1 = false;
             if (MODE == 2) {
                 if (fA & ORBM_MP_PRESENT) continue;                                       // :932
-                st1 = A.uright[idxA] >= 0;
+                st1 = __builtin_amdgcn_readlane(lq_st, src) != 0;
                 if (only_stereo && !st1) continue;                                        // :939-941
             } else {
                 if (!(fA & ORBM_MP_PRESENT) || (fA & ORBM_MP_BAD)) continue;              // :263-267 / :746-749
             }
             uint32_t q[8];
-            load_row(A.desc, idxA, q);
-            const float x1 = MODE == 2 ? A.x[idxA] : 0.f, y1 = MODE == 2 ? A.y[idxA] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = (uint32_t)__builtin_amdgcn_readlane((int)lq[i], src);
+            const float x1 = MODE == 2 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lq_x), src)) : 0.f;
+            const float y1 = MODE == 2 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lq_y), src)) : 0.f;
             uint32_t best = INITKEY, second = INITKEY;
             for (uint32_t cb = 0; cb < nB; cb += 64) {
                 const uint32_t c = cb + lane;
@@ -175,6 +196,9 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
                     best = min(best, key);
                 }
             }
+            // Nothing can be accepted unless some lane holds a distance within the threshold (:304 / :792 / :993):
+            // one ballot saves the cross-lane top-2 reduction for every query without a plausible match.
+            if (!__any((best >> 16) <= (uint32_t)(MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW))) continue;
             if (MODE == 2) {
                 best = wave_min(best);
                 if (best != INITKEY) {                                                    // bestIdx2 >= 0  (:1021)

@@ -9,11 +9,11 @@ with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-def counters(sub):
+def counters(sub, kern="bf2nn"):
     f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "bf2nn" in r["Kernel_Name"]:
+        if kern in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 fetch, nf = counters("fetch"); write, _ = counters("write"); sq, _ = counters("sq")
@@ -29,6 +29,18 @@ summ = {"tag": tag, "kernel": bf["Name"][:80], "launches_profiled": int(bf["Call
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg_bytes, "sq": sq,
         "valu_insts_per_wave_cmp": sq.get("SQ_INSTS_VALU", 0) / (P * 2048 / 64 * N) if sq else None,
         "clock_ghz_est": sq.get("GRBM_GUI_ACTIVE", 0) / 8 / float(bf["AverageNs"]) if sq else None}
+# secondary kernels (bench.py `extra`): windowed SearchByProjection (256 x 50k queries) and SearchByBoW (8192 pairs)
+try:
+    wf, _ = counters("fetch", "window_kernel"); ww, _ = counters("write", "window_kernel")
+    wk = [r for r in rows if "window_kernel" in r["Name"]][0]
+    summ["window_kernel"] = {"name": wk["Name"][:70], "avg_ns": float(wk["AverageNs"]), "FETCH_SIZE_KiB_raw": wf["FETCH_SIZE"],
+                             "WRITE_SIZE_KiB_raw": ww["WRITE_SIZE"], "hbm_bytes_per_launch": (2 * wf["FETCH_SIZE"] + ww["WRITE_SIZE"]) * 1024,
+                             "algorithmic_bytes_per_launch": 256 * (50000 * 53 + 2000 * 49 + 3073 * 4 + 2000 * 4),
+                             "note": "bench extra reuses ONE query set for the 256 instances, so most query bytes come from L2/MALL"}
+    bk = [r for r in rows if "bow_kernel" in r["Name"]][0]
+    summ["bow_kernel"] = {"name": bk["Name"][:70], "avg_ns": float(bk["AverageNs"]), "pairs_per_launch": 8192}
+except Exception as e:
+    summ["secondary_error"] = repr(e)
 json.dump({"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_summary.json"}, open(f"profiles/{tag}_bf2nn_traffic.json", "w"))
 json.dump(summ, open(f"profiles/{tag}_bench_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
