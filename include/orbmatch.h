@@ -198,6 +198,16 @@ int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t 
                              const uint8_t *slot_flags, int32_t stride, int32_t *owner,
                              int32_t *counts, int io_on_device);
 
+/* ---- a12: claim-free best-1 windowed search: the inner loops of SearchBySim3 (ORBmatcher.cc:1586-1626,
+ * 1676-1710) and of both Fuse overloads (:1185-1257, :1390-1421).  KeyFrame grid (KeyFrame.cc:766-812), octave in
+ * [min_level, max_level], strict-< best-1; queries are independent (no slot state is read or written).
+ * chi2_gate != 0 adds Fuse's reprojection gate (:1212-1238): with uRight >= 0,
+ * (ex^2+ey^2+er^2)*invSigma2[octave] > 7.8 skips, else (ex^2+ey^2)*invSigma2[octave] > 5.99 skips (ur from the
+ * query set).  best_idx[k*stride_q + q] = keypoint index if its distance <= dist_th, else -1.  The pointer-graph
+ * side effects of Fuse (Replace / AddObservation, :1259-1283) are replayed on the host in query order. */
+int orbm_search_window_free_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset, int dist_th,
+                                  int chi2_gate, int32_t stride_q, int32_t *best_idx, int io_on_device);
+
 /* ---- a5: SearchForInitialization (ORBmatcher.cc:562-689) --------------------------------------
  * prev_xy: n1 x 2 floats, vbPrevMatched, in/out (:684-686); matches12: n1 ints, -1 = none.
  * Host pointers.  Returns nmatches. */

@@ -46,6 +46,7 @@ def lib():
         L.orc_search_triang.argtypes = [FV, FV, f32p, f32p, C.c_int, C.c_int, i32p, u64p]
         L.orc_search_proj_points.argtypes = [FV, PQ, C.c_float, C.c_float, u8p, i32p, u64p]
         L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
+        L.orc_search_window_free.argtypes = [FV, WQ, C.c_int, C.c_int, i32p, u64p]
         L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         _lib = L
@@ -143,6 +144,14 @@ def search_window(mode, f, q, dist_th, check_ori, slot_flags=None):
     cnt = lib().orc_search_window(mode, C.byref(vf), C.byref(vq), dist_th, int(check_ori), _p(sf, C.c_uint8),
                                   _p(owner, C.c_int32), C.byref(ncmp))
     return int(cnt), owner[:f.n], int(ncmp.value)
+
+
+def search_window_free(f, q, dist_th, chi2_gate):
+    best = np.zeros(max(q.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    vf, vq = f.view(), q.view()
+    lib().orc_search_window_free(C.byref(vf), C.byref(vq), dist_th, int(chi2_gate), _p(best, C.c_int32), C.byref(ncmp))
+    return best[:q.n], int(ncmp.value)
 
 
 def search_init(f1, f2, prev_xy, window, ratio, check_ori):

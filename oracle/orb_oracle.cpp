@@ -500,6 +500,50 @@ int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries
     return nmatches;
 }
 
+// a12: the claim-free best-1 inner loop of SearchBySim3 (:1586-1626) and Fuse (:1185-1257 with the chi-square gate,
+// :1390-1421 without).  best_idx[q] = keypoint or -1 (distance above dist_th or no candidate).
+int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int chi2_gate,
+                           int32_t *best_idx, uint64_t *ncmp) {
+    Counter cnt;
+    Grid g(F);
+    std::vector<int> vIndices;
+    for (int i = 0; i < Q->n; i++) {
+        best_idx[i] = -1;
+        const uint8_t qf = Q->flags ? Q->flags[i] : (uint8_t)(ORBM_Q_VALID | ORBM_Q_OBS);
+        if (!(qf & ORBM_Q_VALID)) continue;
+        const float u = Q->u[i], v = Q->v[i], radius = Q->radius[i];
+        const int minL = Q->min_level[i], maxL = Q->max_level[i];
+        features_in_area(F, g.off.data(), g.idx.data(), u, v, radius, -1, -1, 1, vIndices);
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = Q->desc + (size_t)i * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int idx : vIndices) {
+            const int kpLevel = F->octave[idx];
+            if (kpLevel < minL || kpLevel > maxL) continue;              // :1207 / :1406 / :1608
+            if (chi2_gate) {
+                const float invSigma2 = 1.0f / F->level_sigma2[kpLevel];   // mvInvLevelSigma2 (ORBextractor.cc:479)
+                if (uright(F, idx) >= 0) {                                 // :1212-1225
+                    const float ex = u - F->x[idx];
+                    const float ey = v - F->y[idx];
+                    const float er = Q->ur[i] - uright(F, idx);
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invSigma2 > 7.8) continue;
+                } else {                                                   // :1226-1238
+                    const float ex = u - F->x[idx];
+                    const float ey = v - F->y[idx];
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invSigma2 > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(dMP, row(F, idx), cnt);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= dist_th) best_idx[i] = bestIdx;                    // :1257 / :1421 / :1622
+    }
+    if (ncmp) *ncmp = cnt.n;
+    return 0;
+}
+
 // a5, ORBmatcher.cc:562-689
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize,
                     float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp) {

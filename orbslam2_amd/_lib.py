@@ -14,7 +14,8 @@ SYMBOLS = [
     "orbm_frames_upload", "orbm_frames_free", "orbm_frame_set_mp_flags", "orbm_frame_grid_download",
     "orbm_proj_queries_upload", "orbm_win_queries_upload", "orbm_queries_free",
     "orbm_hamming256_pairs", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
-    "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_init", "orbm_popcount_peak",
+    "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
+    "orbm_popcount_peak",
 ]
 
 _lib = None
@@ -53,6 +54,7 @@ def load():
     L.orbm_search_triang_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, i32, vp, vp, C.c_int]
     L.orbm_search_proj_points_batch.argtypes = [vp, C.c_int, vp, vp, f32, f32, vp, i32, vp, vp, C.c_int]
     L.orbm_search_window_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, i32, vp, vp, C.c_int]
+    L.orbm_search_window_free_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, i32, vp, C.c_int]
     L.orbm_search_init.argtypes = [vp, i32, i32, vp, C.c_int, f32, C.c_int, vp]
     L.orbm_popcount_peak.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in SYMBOLS:

@@ -401,6 +401,53 @@ __global__ void window_kernel(WinParams P) {
     if (tid == 0) P.counts[inst] = *nmatch;
 }
 
+// a12: claim-free best-1 (SearchBySim3 / Fuse inner loops).  Queries are independent: one lane per query, grid =
+// instances x query chunks, frame read through L2 (cell-ordered records stream contiguously).
+__global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_inst, int chi2_gate) {
+    const int inst = blockIdx.x / chunks_per_inst;
+    const int chunk = blockIdx.x - inst * chunks_per_inst;
+    const FrameDev &F = P.frames[P.frame_ids[inst]];
+    const QSetDev &QS = P.qsets[P.qset_ids[inst]];
+    const int qi = chunk * 256 + (int)threadIdx.x;
+    if (qi >= QS.n) return;
+    int32_t *out = P.out + (size_t)inst * P.stride;
+    int result = -1;
+    if (QS.flags[qi] & ORBM_Q_VALID) {
+        FrameAcc acc;
+        acc.min_x = F.min_x; acc.min_y = F.min_y; acc.inv_w = F.inv_w; acc.inv_h = F.inv_h;
+        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = reinterpret_cast<const uint4 *>(F.desc);
+        const float u = QS.f0[qi], v = QS.f1[qi], radius = QS.f2[qi];
+        const float ur = QS.f3 ? QS.f3[qi] : 0.f;
+        const int minL = QS.l0[qi], maxL = QS.l1[qi];
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(QS.desc) + 2 * (size_t)qi;
+        const uint4 d0 = p4[0], d1 = p4[1];
+        const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        int bestDist = INT_MAX, bestIdx = -1;
+        auto body = [&](int k, int oct, float kur) {
+            if (oct < minL || oct > maxL) return;                                          // :1207 / :1406 / :1608
+            if (chi2_gate) {
+                const float inv = __fdiv_rn(1.0f, F.sigma2[oct]);
+                const float ex = __fsub_rn(u, F.x[k]), ey = __fsub_rn(v, F.y[k]);
+                if (kur >= 0) {                                                            // :1212-1225
+                    const float er = __fsub_rn(ur, kur);
+                    const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                    if ((double)__fmul_rn(e2, inv) > 7.8) return;
+                } else {                                                                   // :1226-1238
+                    const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    if ((double)__fmul_rn(e2, inv) > 5.99) return;
+                }
+            }
+            const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+            const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int dist = (int)hamming256(qd, cd);
+            if (dist < bestDist) { bestDist = dist; bestIdx = k; }
+        };
+        walk_window<true>(acc, u, v, radius, -1, -1, body);
+        if (bestDist <= P.dist_th) result = bestIdx;
+    }
+    out[qi] = result;
+}
+
 constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint <= 160 KB
 
 template <int MODE, bool LDS_FRAME>
@@ -535,4 +582,46 @@ extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, f
     HIPCHK(ctx, hipMemcpyAsync(matches12, d_m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return count;
+}
+
+extern "C" int orbm_search_window_free_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
+                                             int dist_th, int chi2_gate, int32_t stride_q, int32_t *best_idx,
+                                             int io_on_device) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_inst < 0 || (n_inst > 0 && (!frame || !qset || !best_idx)) || stride_q < 0)
+        return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_batch: null argument or negative size");
+    if (n_inst == 0 || stride_q == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!io_on_device) {
+        int rc = orbm_check_frames(ctx, n_inst, frame, "frame");
+        if (!rc) rc = orbm_check_qsets(ctx, n_inst, qset, 1, "qset");
+        if (rc) return rc;
+        for (int k = 0; k < n_inst; k++) {
+            if (ctx->h_qsets[qset[k]].n > stride_q)
+                return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_batch: stride_q %d < %d queries of instance %d", stride_q, ctx->h_qsets[qset[k]].n, k);
+            if (chi2_gate && ctx->h_qsets[qset[k]].n > 0 && !ctx->h_qsets[qset[k]].f3)
+                return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_batch: chi2_gate needs the query set's ur array");
+        }
+    }
+    const size_t out_elems = (size_t)n_inst * stride_q;
+    IoStage io(ctx, io_on_device);
+    if (!io_on_device) {
+        int rc = orbm_ws_reserve(ctx, (size_t)n_inst * 8 + out_elems * 4 + 4096);
+        if (rc) return rc;
+    }
+    const void *dfr, *dqs; void *dout;
+    int rc;
+    if ((rc = io.in(frame, (size_t)n_inst * 4, &dfr)) || (rc = io.in(qset, (size_t)n_inst * 4, &dqs)) ||
+        (rc = io.out(best_idx, out_elems * 4, &dout)))
+        return rc;
+    HIPCHK(ctx, hipMemsetAsync(dout, 0xFF, out_elems * 4, ctx->stream));   // rows beyond a set's n stay -1
+    WinParams P;
+    memset(&P, 0, sizeof P);
+    P.frames = ctx->d_frames; P.qsets = ctx->d_qsets;
+    P.frame_ids = (const int32_t *)dfr; P.qset_ids = (const int32_t *)dqs;
+    P.out = (int32_t *)dout; P.dist_th = dist_th; P.stride = stride_q;
+    const int chunks = (stride_q + 255) / 256;
+    hipLaunchKernelGGL(free_kernel, dim3((unsigned)(n_inst * chunks)), dim3(256), 0, ctx->stream, P, chunks, chi2_gate);
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
 }

@@ -214,6 +214,16 @@ class Context:
                                                    _addr(sf), stride, _addr(owner), _addr(counts), 0))
         return counts[:k], owner[:k]
 
+    # ---- a12 ----
+    def search_window_free(self, frames, qsets, dist_th: int, chi2_gate: bool, stride_q: int):
+        fr = np.ascontiguousarray(frames, np.int32)
+        qs = np.ascontiguousarray(qsets, np.int32)
+        k = len(fr)
+        best = np.full((max(k, 1), max(stride_q, 1)), -1, np.int32)
+        self._chk(self._L.orbm_search_window_free_batch(self._h, k, _addr(fr), _addr(qs), dist_th, int(chi2_gate),
+                                                        stride_q, _addr(best), 0))
+        return best[:k]
+
     # ---- a5 ----
     def search_init(self, f1: int, f2: int, prev_xy: np.ndarray, window: int, ratio: float, check_ori: bool):
         prev = np.ascontiguousarray(prev_xy, np.float32).copy()

@@ -237,3 +237,26 @@ def test_frames_over_the_window_limit_are_rejected(ctx):
     with pytest.raises(OrbmError):
         ctx.search_proj_points(fid, qid, 3.0, 0.8, stride=9000)
     ctx.free_frames(fid); ctx.free_queries(qid)
+
+
+@pytest.mark.parametrize("chi2,dist_th,stereo", [(False, 100, False), (True, 50, True), (True, 50, False), (False, 50, True)])
+def test_window_free_parity(ctx, orc, chi2, dist_th, stereo):
+    """a12: claim-free best-1 (SearchBySim3 / Fuse inner loops), with and without the chi-square gate."""
+    insts = []
+    for k in range(3):
+        f, q = synth.window_instance(950 + k + 10 * chi2, 2, n=[2000, 3000, 40][k], n_queries=[2500, 700, 300][k],
+                                     stereo=stereo, th=[10.0, 3.0, 10.0][k])
+        rng = np.random.default_rng(k)
+        src_ur = np.where(rng.random(q.n) < 0.8, rng.uniform(0, 600, q.n), -1.0).astype(np.float32)
+        q.ur = src_ur                      # u - bf*invz of the query (Fuse's stereo residual)
+        insts.append((f, q))
+    fids = ctx.upload_frames([i[0] for i in insts]); qids = ctx.upload_win_queries([i[1] for i in insts])
+    best = ctx.search_window_free(fids, qids, dist_th, chi2, stride_q=2500)
+    tot = 0
+    for k, (f, q) in enumerate(insts):
+        wb, _ = orc.search_window_free(f, q, dist_th, chi2)
+        assert np.array_equal(best[k, :q.n], wb), k
+        assert (best[k, q.n:] == -1).all()
+        tot += (wb >= 0).sum()
+    assert tot > 200
+    ctx.free_frames(fids); ctx.free_queries(qids)
