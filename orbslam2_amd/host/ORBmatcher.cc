@@ -123,15 +123,19 @@ struct WinQ {
     vector<int32_t> minL, maxL;
     explicit WinQ(int n) : desc((size_t)n * 32, 0), flags(n, 0), u(n, 0), v(n, 0), radius(n, 0), ur(n, 0), angle(n, 0), minL(n, 0), maxL(n, 0) {}
     void SetDesc(int i, const cv::Mat &d) { memcpy(&desc[(size_t)i * 32], d.ptr<uint8_t>(), 32); }
-    // runs orbm_search_window_batch for one instance; returns nmatches, owner[] sized n_slots
-    int Run(int mode, int32_t frame_id, int n_slots, int dist_th, bool check_ori, bool with_ur, bool with_angle,
-            const uint8_t *slot_flags, vector<int32_t> &owner) {
+    orbm_win_queries View(bool with_ur, bool with_angle) const {
         orbm_win_queries q;
         memset(&q, 0, sizeof q);
         q.n = (int)flags.size();
         q.desc = desc.data(); q.u = u.data(); q.v = v.data(); q.radius = radius.data();
         q.min_level = minL.data(); q.max_level = maxL.data();
         q.ur = with_ur ? ur.data() : nullptr; q.angle = with_angle ? angle.data() : nullptr; q.flags = flags.data();
+        return q;
+    }
+    // runs orbm_search_window_batch for one instance; returns nmatches, owner[] sized n_slots
+    int Run(int mode, int32_t frame_id, int n_slots, int dist_th, bool check_ori, bool with_ur, bool with_angle,
+            const uint8_t *slot_flags, vector<int32_t> &owner) {
+        orbm_win_queries q = View(with_ur, with_angle);
         int32_t qid = -1, count = 0;
         Check(orbm_win_queries_upload(Ctx(), 1, &q, &qid), "orbm_win_queries_upload");
         owner.assign(max(n_slots, 1), -1);
@@ -142,6 +146,36 @@ struct WinQ {
         return count;
     }
 };
+
+// claim-free best-1 (orbm_search_window_free_batch) of several (frame, query set) instances in one launch;
+// best[k][i] = keypoint of frame k matched to query i, or -1
+void RunFree(const vector<const WinQ *> &qs, const vector<int32_t> &frame_ids, int dist_th, bool chi2, vector<vector<int32_t>> &best) {
+    const int K = (int)qs.size();
+    vector<orbm_win_queries> views(K);
+    int stride = 1;
+    for (int k = 0; k < K; k++) { views[k] = qs[k]->View(true, false); stride = max(stride, views[k].n); }
+    vector<int32_t> qid(K, -1), flat((size_t)K * stride, -1);
+    Check(orbm_win_queries_upload(Ctx(), K, views.data(), qid.data()), "orbm_win_queries_upload");
+    int rc = orbm_search_window_free_batch(Ctx(), K, frame_ids.data(), qid.data(), dist_th, chi2 ? 1 : 0, stride, flat.data(), 0);
+    orbm_queries_free(Ctx(), K, qid.data());
+    Check(rc, "orbm_search_window_free_batch");
+    best.resize(K);
+    for (int k = 0; k < K; k++) best[k].assign(flat.begin() + (size_t)k * stride, flat.begin() + (size_t)k * stride + views[k].n);
+}
+
+// Scw -> Rcw, tcw, Ow (ORBmatcher.cc:411-415 / 1313-1317).  cv::Mat / scalar is a convertTo with alpha = 1/scw; for
+// CV_32F -> CV_32F OpenCV applies alpha in float.
+void DecomposeSim3(const cv::Mat &Scw, float *Rcw, float *tcw, float *Ow) {
+    const float *S = Scw.ptr<float>();
+    const float row0[3] = {S[0], S[1], S[2]};
+    const float scw = sqrt(orbm_host::dot3(row0, row0));
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Rcw[3 * r + c] = S[4 * r + c] * inv;
+        tcw[r] = S[4 * r + 3] * inv;
+    }
+    orbm_host::gemm3(Rcw, 3, true, tcw, -1.0, nullptr, Ow);
+}
 
 }  // namespace
 
@@ -376,17 +410,8 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
 int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, vector<MapPoint *> &vpMatched, int th) {
     if (pKF->N == 0 || vpPoints.empty()) return 0;
     const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
-    // decompose Scw (:411-415): sRcw / scw with the scalar applied as a double reciprocal, as cv::Mat does
-    const float *S = Scw.ptr<float>();
-    const float row0[3] = {S[0], S[1], S[2]};
-    const float scw = sqrt(orbm_host::dot3(row0, row0));
-    const double inv = 1.0 / (double)scw;
     float Rcw[9], tcw[3], Ow[3];
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) Rcw[3 * r + c] = (float)((double)S[4 * r + c] * inv);
-        tcw[r] = (float)((double)S[4 * r + 3] * inv);
-    }
-    orbm_host::gemm3(Rcw, 3, true, tcw, -1.0, nullptr, Ow);
+    DecomposeSim3(Scw, Rcw, tcw, Ow);                                                     // :411-415
     set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());
     spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
 
@@ -428,6 +453,196 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapP
     for (int idx = 0; idx < pKF->N; idx++)
         if (owner[idx] >= 0) vpMatched[idx] = vpPoints[owner[idx]];                       // :535
     return n;
+}
+
+// ---- ORBmatcher.cc:1468-1752 --------------------------------------------------------------------------------------
+int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
+                             const cv::Mat &t12, const float th) {
+    const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;          // :1471-1474 (KF1's for both directions)
+    cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation();
+    cv::Mat R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    // :1485-1487.  scalar * Mat is a float convertTo; -sR21*t12 is one gemm with alpha = -1
+    float sR12[9], sR21[9], t21[3];
+    const float *r12 = R12.ptr<float>();
+    const float inv_s = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12[3 * r + c] = s12 * r12[3 * r + c]; sR21[3 * r + c] = r12[3 * c + r] * inv_s; }
+    orbm_host::gemm3(sR21, 3, false, t12.ptr<float>(), -1.0, nullptr, t21);
+
+    const vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size();
+    const vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = (int)vpMapPoints2.size();
+    vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {                                                        // :1500-1510
+        MapPoint *pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    if (N1 == 0 || N2 == 0 || pKF1->N == 0 || pKF2->N == 0) return 0;
+
+    // one direction: points of `src` (world -> its camera by Rsw, tsw -> the other camera by sR, t) searched in pKFdst
+    auto build = [&](WinQ &q, const vector<MapPoint *> &pts, const vector<bool> &done, const cv::Mat &Rsw, const cv::Mat &tsw,
+                     const float *sR, const float *t, KeyFrame *pKFdst) {
+        for (size_t i = 0; i < pts.size(); i++) {
+            MapPoint *pMP = pts[i];
+            if (!pMP || done[i]) continue;                                                // :1527
+            if (pMP->isBad()) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            float pa[3], pb[3];
+            orbm_host::gemm3(Rsw.ptr<float>(), 3, false, p3Dw.ptr<float>(), 1.0, tsw.ptr<float>(), pa);   // :1534
+            orbm_host::gemm3(sR, 3, false, pa, 1.0, t, pb);                                                // :1535
+            if (pb[2] < 0.0) continue;
+            const float invz = 1.0 / pb[2];
+            const float x = pb[0] * invz, y = pb[1] * invz;
+            const float u = fx * x + cx, v = fy * y + cy;
+            if (!pKFdst->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = orbm_host::norm3(pb);                                    // :1562
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKFdst);
+            q.radius[i] = th * pKFdst->mvScaleFactors[nPredictedLevel];                   // :1582
+            q.minL[i] = nPredictedLevel - 1; q.maxL[i] = nPredictedLevel;                 // :1608
+            q.u[i] = u; q.v[i] = v;
+            q.flags[i] = ORBM_Q_VALID | ORBM_Q_OBS;
+            q.SetDesc((int)i, pMP->GetDescriptor());
+        }
+    };
+    WinQ q1(N1), q2(N2);
+    build(q1, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2);
+    build(q2, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12.ptr<float>(), pKF1);
+    Flat f1, f2;
+    Flatten(f1, pKF1);
+    Flatten(f2, pKF2);
+    Uploaded up({&f1.v, &f2.v});
+    vector<vector<int32_t>> best;
+    RunFree({&q1, &q2}, {up.ids[1], up.ids[0]}, TH_HIGH, false, best);                   // both directions, one launch
+    const vector<int32_t> &vnMatch1 = best[0], &vnMatch2 = best[1];
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {                                                     // :1736-1749
+        int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) {
+                vpMatches12[i1] = vpMapPoints2[idx2];
+                nFound++;
+            }
+        }
+    }
+    return nFound;
+}
+
+namespace {
+// the projection gates both Fuse overloads share (:1140-1183 / :1341-1386); ur is only read by the chi-square gate
+void FuseQueries(WinQ &q, KeyFrame *pKF, const vector<MapPoint *> &pts, const vector<char> &skip, const float *Rcw, const float *tcw,
+                 const float *Ow, float bf, float th) {
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    for (size_t i = 0; i < pts.size(); i++) {
+        MapPoint *pMP = pts[i];
+        if (skip[i]) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        float p3Dc[3];
+        orbm_host::gemm3(Rcw, 3, false, p3Dw.ptr<float>(), 1.0, tcw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float ur = u - bf * invz;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const float *pw = p3Dw.ptr<float>();
+        const float PO[3] = {pw[0] - Ow[0], pw[1] - Ow[1], pw[2] - Ow[2]};
+        const float dist3D = orbm_host::norm3(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (orbm_host::dot3(PO, Pn.ptr<float>()) < 0.5 * dist3D) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        q.radius[i] = th * pKF->mvScaleFactors[nPredictedLevel];
+        q.minL[i] = nPredictedLevel - 1; q.maxL[i] = nPredictedLevel;
+        q.u[i] = u; q.v[i] = v; q.ur[i] = ur;
+        q.flags[i] = ORBM_Q_VALID | ORBM_Q_OBS;
+        q.SetDesc((int)i, pMP->GetDescriptor());
+    }
+}
+}  // namespace
+
+// ---- ORBmatcher.cc:1111-1288 --------------------------------------------------------------------------------------
+int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th) {
+    const int nMPs = (int)vpMapPoints.size();
+    if (nMPs == 0 || pKF->N == 0) return 0;
+    cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+    // A point that fails `!pMP || isBad() || IsInKeyFrame(pKF)` (:1134-1138) now also fails it when the reference's loop
+    // reaches it: Replace only ever makes points bad or adds them to pKF.  So it is safe to drop them before the launch.
+    vector<char> skip(nMPs, 0);
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        skip[i] = !pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF);
+    }
+    WinQ q(nMPs);
+    FuseQueries(q, pKF, vpMapPoints, skip, Rcw.ptr<float>(), tcw.ptr<float>(), Ow.ptr<float>(), pKF->mbf, th);
+    Flat f;
+    Flatten(f, pKF);
+    Uploaded up({&f.v});
+    vector<vector<int32_t>> best;
+    RunFree({&q}, {up.ids[0]}, TH_LOW, true, best);
+    // replay of the reference loop, in order, with the state-dependent gates evaluated now
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;                             // :1137
+        const int bestIdx = best[0][i];
+        if (bestIdx < 0) continue;                                                        // gates, empty window or bestDist > TH_LOW
+        MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);                                    // :1259
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+// ---- ORBmatcher.cc:1301-1443 --------------------------------------------------------------------------------------
+int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint) {
+    const int nPoints = (int)vpPoints.size();
+    if (nPoints == 0 || pKF->N == 0) return 0;
+    float Rcw[9], tcw[3], Ow[3];
+    DecomposeSim3(Scw, Rcw, tcw, Ow);                                                     // :1313-1317
+    const set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();                           // :1320, a snapshot in the reference too
+    vector<char> skip(nPoints, 0);
+    for (int i = 0; i < nPoints; i++) skip[i] = vpPoints[i]->isBad() || spAlreadyFound.count(vpPoints[i]);   // :1337 (nothing here makes a point bad)
+    WinQ q(nPoints);
+    FuseQueries(q, pKF, vpPoints, skip, Rcw, tcw, Ow, 0.f, th);
+    Flat f;
+    Flatten(f, pKF);
+    Uploaded up({&f.v});
+    vector<vector<int32_t>> best;
+    RunFree({&q}, {up.ids[0]}, TH_LOW, false, best);
+    int nFused = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        const int bestIdx = best[0][iMP];
+        if (bestIdx < 0) continue;
+        MapPoint *pMP = vpPoints[iMP];
+        MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);                                    // :1423, sees slots filled earlier in this loop
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
 }
 
 }  // namespace ORB_SLAM2

@@ -9,7 +9,9 @@
 // equals what the reference reads because its callers hold Map::mMutexMapUpdate or work on local copies
 // ("Pointer graph <-> flat arrays").
 //
-// Not yet ported ("next"): SearchBySim3 and the two Fuse overloads.
+// Fuse mutates the map while it iterates (MapPoint::Replace / AddObservation).  The search itself reads none of
+// that state, so it runs as one launch; the host then replays the reference's loop in order with the gates that
+// do depend on it (isBad, IsInKeyFrame, the slot's current map point) evaluated at replay time.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -37,6 +39,14 @@ public:
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
     // ORBmatcher.cc:401-542 (LoopClosing::ComputeSim3)
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
+
+    // ORBmatcher.cc:1468-1752 (LoopClosing::ComputeSim3)
+    int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
+                     const cv::Mat &t12, const float th);
+    // ORBmatcher.cc:1111-1288 (LocalMapping::SearchInNeighbors)
+    int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0);
+    // ORBmatcher.cc:1301-1443 (LoopClosing::SearchAndFuse)
+    int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint);
 
     // ORBmatcher.cc:218-385 and 703-854
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);

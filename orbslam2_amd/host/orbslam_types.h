@@ -41,6 +41,18 @@ public:
         return it == mObservations.end() ? -1 : (int)it->second;
     }
     bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
+    // the two mutators Fuse calls (MapPoint.cc:141-158, 255-311); defined after KeyFrame below
+    void AddObservation(KeyFrame *pKF, size_t idx);
+    void Replace(MapPoint *pMP);
+    MapPoint *GetReplaced() { return mpReplaced; }
+    void IncreaseVisible(int n = 1) { mnVisible += n; }
+    void IncreaseFound(int n = 1) { mnFound += n; }
+    // MapPoint.cc:323-398 (median-distance descriptor over all observations) belongs to the map, not the matcher:
+    // the stand-in keeps mDescriptor as it is.
+    void ComputeDistinctiveDescriptors() {}
+
+    MapPoint() { static long unsigned int nNextId = 0; mnId = nNextId++; }
+    long unsigned int mnId;
 
     // tracking scratch fields written by Frame::isInFrustum (MapPoint.h:183-198)
     float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
@@ -54,6 +66,8 @@ public:
     int nObs = 0;
     bool mbBad = false;
     float mfMinDistance = 0, mfMaxDistance = 0;
+    int mnVisible = 1, mnFound = 1;
+    MapPoint *mpReplaced = nullptr;
 };
 
 class Frame {
@@ -98,7 +112,9 @@ public:
         for (MapPoint *p : mvpMapPoints) if (p && !p->isBad()) s.insert(p);
         return s;
     }
-    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }                    // KeyFrame.cc:285
+    void EraseMapPointMatch(const size_t &idx) { mvpMapPoints[idx] = static_cast<MapPoint *>(NULL); }  // KeyFrame.cc:294
+    void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }           // KeyFrame.cc:309
     cv::Mat GetRotation() { return Rcw.clone(); }       // 3x3 CV_32F
     cv::Mat GetTranslation() { return tcw.clone(); }    // 3x1
     cv::Mat GetCameraCenter() { return Ow.clone(); }    // 3x1
@@ -107,6 +123,36 @@ public:
     std::vector<MapPoint *> mvpMapPoints;
     cv::Mat Rcw, tcw, Ow;
 };
+
+// MapPoint.cc:141-158
+inline void MapPoint::AddObservation(KeyFrame *pKF, size_t idx) {
+    if (mObservations.count(pKF)) return;
+    mObservations[pKF] = idx;
+    if (pKF->mvuRight[idx] >= 0) nObs += 2;
+    else nObs++;
+}
+
+// MapPoint.cc:255-311 (without the Map bookkeeping of :310)
+inline void MapPoint::Replace(MapPoint *pMP) {
+    if (pMP->mnId == this->mnId) return;
+    std::map<KeyFrame *, size_t> obs = mObservations;
+    mObservations.clear();
+    mbBad = true;
+    const int nvisible = mnVisible, nfound = mnFound;
+    mpReplaced = pMP;
+    for (auto mit = obs.begin(), mend = obs.end(); mit != mend; mit++) {
+        KeyFrame *pKF = mit->first;
+        if (!pMP->IsInKeyFrame(pKF)) {
+            pKF->ReplaceMapPointMatch(mit->second, pMP);
+            pMP->AddObservation(pKF, mit->second);
+        } else {
+            pKF->EraseMapPointMatch(mit->second);
+        }
+    }
+    pMP->IncreaseFound(nfound);
+    pMP->IncreaseVisible(nvisible);
+    pMP->ComputeDistinctiveDescriptors();
+}
 
 // MapPoint.cc:569-602.  `using namespace std` reaches MapPoint.cc through the DBoW2 headers, so log(float)
 // and ceil(float) are the float overloads.

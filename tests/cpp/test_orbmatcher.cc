@@ -22,6 +22,7 @@ int orc_search_bow(int variant, const orbm_frame_view *A, const orbm_frame_view 
 int orc_search_triang(const orbm_frame_view *A, const orbm_frame_view *B, const float *f12, const float *epipole, int only_stereo, int check_ori, int32_t *match12, uint64_t *ncmp);
 int orc_search_proj_points(const orbm_frame_view *F, const orbm_proj_queries *Q, float th, float ratio, const uint8_t *slot_flags, int32_t *owner, uint64_t *ncmp);
 int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int check_ori, const uint8_t *slot_flags, int32_t *owner, uint64_t *ncmp);
+int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int chi2_gate, int32_t *best_idx, uint64_t *ncmp);
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize, float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp);
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels);
 }
@@ -390,6 +391,208 @@ static void TestWindowOverloads() {
     printf("SearchByProjection x3 (Last / KF / Sim3) done\n");
 }
 
+// Place map point p in front of an identity-pose camera so that it projects next to keypoint s of `rt`, with a
+// descriptor observing the same landmark and a scale-invariance range that predicts the keypoint's octave.
+static void PlaceNear(MapPoint *p, const Raw &rt, int s, const vector<Desc> &lm, double lvl_lo, double lvl_hi) {
+    const float fx = 500, fy = 510, cx = 320, cy = 240;
+    float Z = (float)U(2, 8);
+    float tu = rt.x[s] + (float)Nrm(2), tv = rt.y[s] + (float)Nrm(2);
+    if (U(0, 1) < 0.03) tu = -50;
+    float X = (tu - cx) / fx * Z, Y = (tv - cy) / fy * Z;
+    if (U(0, 1) < 0.03) Z = -Z;
+    p->mWorldPos.at<float>(0) = X; p->mWorldPos.at<float>(1) = Y; p->mWorldPos.at<float>(2) = Z;
+    Desc d = Observe(lm[rt.lm[s]], 0.06);
+    memcpy(p->mDescriptor.ptr<uint8_t>(), d.b, 32);
+    float d3 = std::sqrt((double)X * X + (double)Y * Y + (double)Z * Z);
+    p->mfMaxDistance = d3 * std::pow(1.2f, (float)rt.octave[s] + (float)U(lvl_lo, lvl_hi)) / 1.2f;
+    p->mfMinDistance = p->mfMaxDistance / std::pow(1.2f, 7.f);
+    if (U(0, 1) < 0.05) p->mfMaxDistance = d3 * 0.5f;
+    p->mNormalVector.at<float>(0) = X / d3; p->mNormalVector.at<float>(1) = Y / d3; p->mNormalVector.at<float>(2) = Z / d3;
+    if (U(0, 1) < 0.05) p->mNormalVector.at<float>(2) = -Z / d3;
+}
+
+// Flat query of one map point against an identity-pose keyframe `rt` (the formulas of ORBmatcher.cc:1140-1183 / 1533-1582).
+struct FlatQ {
+    vector<Desc> d; vector<float> u, v, rad, ur; vector<int32_t> mn, mx; vector<uint8_t> f;
+    explicit FlatQ(int n) : d(n), u(n, 0), v(n, 0), rad(n, 0), ur(n, 0), mn(n, 0), mx(n, 0), f(n, 0) {}
+    void Set(int i, MapPoint *p, const Raw &rt, float th, bool normal_gate) {
+        const float fx = 500, fy = 510, cx = 320, cy = 240, bf = 40;
+        const float X = p->mWorldPos.at<float>(0), Y = p->mWorldPos.at<float>(1), Z = p->mWorldPos.at<float>(2);
+        if (Z < 0.0f) return;
+        const float invz = 1 / Z;
+        const float x = X * invz, y = Y * invz;
+        const float uu = fx * x + cx, vv = fy * y + cy;
+        if (!(uu >= 0 && uu < 640 && vv >= 0 && vv < 480)) return;
+        const float d3 = (float)std::sqrt((double)X * X + (double)Y * Y + (double)Z * Z);
+        if (d3 < 0.8f * p->mfMinDistance || d3 > 1.2f * p->mfMaxDistance) return;
+        const float *nrm = p->mNormalVector.ptr<float>();
+        if (normal_gate && (double)X * nrm[0] + (double)Y * nrm[1] + (double)Z * nrm[2] < 0.5 * d3) return;
+        int l = orc_predict_scale(p->mfMaxDistance, d3, std::log(1.2f), 8);
+        rad[i] = th * rt.sf[l]; mn[i] = l - 1; mx[i] = l; u[i] = uu; v[i] = vv; ur[i] = uu - bf * invz;
+        memcpy(d[i].b, p->mDescriptor.ptr<uint8_t>(), 32);
+        f[i] = ORBM_Q_VALID | ORBM_Q_OBS;
+    }
+    orbm_win_queries view() const {
+        orbm_win_queries q; memset(&q, 0, sizeof q);
+        q.n = (int)f.size(); q.desc = d[0].b; q.u = u.data(); q.v = v.data(); q.radius = rad.data(); q.ur = ur.data();
+        q.min_level = mn.data(); q.max_level = mx.data(); q.flags = f.data();
+        return q;
+    }
+};
+
+static void TestSim3() {
+    vector<Desc> lm(3000); for (auto &d : lm) d = RandDesc();
+    Raw r1 = MakeRaw(1400, lm, 0, 3000, 10, 0.4, 0.8, 0.05, 0.1);
+    Raw r2 = MakeRaw(1300, lm, 0, 3000, 10, 0.4, 0.8, 0.05, 0.1);
+    // the first 700 keypoints see the same landmarks at almost the same place in both keyframes
+    for (int i = 0; i < 700; i++) { r2.lm[i] = r1.lm[i]; r2.desc[i] = Observe(lm[r1.lm[i]], 0.06); r2.x[i] = r1.x[i] + (float)Nrm(1.5); r2.y[i] = r1.y[i] + (float)Nrm(1.5); r2.octave[i] = r1.octave[i]; }
+    KeyFrame A, B; FillKF(A, r1); FillKF(B, r2);
+    for (int i = 0; i < A.N; i++) if (A.mvpMapPoints[i]) { PlaceNear(A.mvpMapPoints[i], r2, i < 700 ? i : RI(r2.n), lm, 0.1, 0.9); A.mvpMapPoints[i]->mObservations[&A] = i; }
+    for (int i = 0; i < B.N; i++) if (B.mvpMapPoints[i]) { PlaceNear(B.mvpMapPoints[i], r1, i < 700 ? i : RI(r1.n), lm, 0.1, 0.9); B.mvpMapPoints[i]->mObservations[&B] = i; }
+    cv::Mat R12 = cv::Mat::eye(3, 3, CV_32F), t12 = cv::Mat::zeros(3, 1, CV_32F);
+    for (float th : {7.5f, 3.0f}) {
+        // matches SearchByBoW would have left: a tenth of KF1's slots already point at a KF2 map point
+        vector<MapPoint *> m12(A.N, nullptr);
+        vector<char> done1(A.N, 0), done2(B.N, 0);
+        for (int i = 0; i < A.N; i++) if (U(0, 1) < 0.1) { int j = RI(B.N); if (B.mvpMapPoints[j]) { m12[i] = B.mvpMapPoints[j]; done1[i] = 1; done2[j] = 1; } }
+        FlatQ q1(A.N), q2(B.N);
+        for (int i = 0; i < A.N; i++) { MapPoint *p = A.mvpMapPoints[i]; if (p && !done1[i] && !p->mbBad) q1.Set(i, p, r2, th, false); }
+        for (int i = 0; i < B.N; i++) { MapPoint *p = B.mvpMapPoints[i]; if (p && !done2[i] && !p->mbBad) q2.Set(i, p, r1, th, false); }
+        orbm_frame_view v1 = r1.view(true), v2 = r2.view(true);
+        orbm_win_queries w1 = q1.view(), w2 = q2.view();
+        vector<int32_t> b1(A.N), b2(B.N); uint64_t nc;
+        orc_search_window_free(&v2, &w1, 100, 0, b1.data(), &nc);
+        orc_search_window_free(&v1, &w2, 100, 0, b2.data(), &nc);
+        vector<MapPoint *> want = m12; int nwant = 0;
+        for (int i = 0; i < A.N; i++) if (b1[i] >= 0 && b2[b1[i]] == i) { want[i] = B.mvpMapPoints[b1[i]]; nwant++; }
+        ORBmatcher matcher(0.75f, true);
+        const float s12 = 1.0f;
+        int cnt = matcher.SearchBySim3(&A, &B, m12, s12, R12, t12, th);
+        EXPECT(cnt == nwant, "sim3 th %.1f count %d vs %d", th, cnt, nwant);
+        int bad = 0; for (int i = 0; i < A.N; i++) bad += m12[i] != want[i];
+        EXPECT(bad == 0, "sim3 %d mismatches", bad);
+        EXPECT(nwant > 100, "sim3 too few mutual matches (%d)", nwant);
+    }
+    printf("SearchBySim3 done\n");
+}
+
+// One world for the Fuse tests: a target keyframe K, a second keyframe K2 that also observes some of the points, and
+// the candidate points.  Built twice from the same random stream: one copy goes through the class, the other is
+// advanced by the reference's loop (restated here, ORBmatcher.cc:1255-1284 / 1421-1439) on the oracle's matches.
+struct FuseWorld {
+    KeyFrame K, K2;
+    vector<MapPoint *> pts;
+    std::map<MapPoint *, int> id;     // stable numbering for comparisons across the two copies
+    int Id(MapPoint *p) { if (!p) return -1; auto it = id.find(p); return it == id.end() ? -9 : it->second; }
+};
+static void BuildFuseWorld(FuseWorld &w, const Raw &rc, const vector<Desc> &lm, int Q, bool allow_null) {
+    FillKF(w.K, rc);
+    w.K2.N = 8000; w.K2.mvuRight.assign(8000, -1.f); w.K2.mvpMapPoints.assign(8000, nullptr);
+    for (int i = 0; i < 8000; i += 3) w.K2.mvuRight[i] = 5.f;
+    int next = 0, slot2 = 0;
+    for (int i = 0; i < w.K.N; i++) if (MapPoint *p = w.K.mvpMapPoints[i]) {
+        w.id[p] = next++;
+        p->nObs = 0; p->AddObservation(&w.K, i);
+        if (U(0, 1) < 0.6) { p->AddObservation(&w.K2, slot2); w.K2.mvpMapPoints[slot2++] = p; }
+        p->nObs += RI(4);
+    }
+    w.pts.assign(Q, nullptr);
+    for (int i = 0; i < Q; i++) {
+        double r = U(0, 1);
+        if (r < 0.04 && allow_null) continue;                               // null entry
+        if (r < 0.10 && i > 10 && (allow_null || w.pts[i - 1])) { int j = RI(i); w.pts[i] = w.pts[j] ? w.pts[j] : w.pts[i - 1]; continue; }   // listed twice
+        if (r < 0.16) {                                                     // already in the keyframe
+            int s = RI(w.K.N);
+            while (!w.K.mvpMapPoints[s]) s = (s + 1) % w.K.N;
+            w.pts[i] = w.K.mvpMapPoints[s];
+            continue;
+        }
+        MapPoint *p = NewMP(ORBM_MP_PRESENT | (U(0, 1) < 0.05 ? ORBM_MP_BAD : 0));
+        w.id[p] = next++;
+        PlaceNear(p, rc, RI(rc.n), lm, 0.1, 0.9);
+        p->nObs = 0;
+        if (U(0, 1) < 0.8) { p->AddObservation(&w.K2, slot2); w.K2.mvpMapPoints[slot2++] = p; }
+        p->nObs += RI(5);
+        w.pts[i] = p;
+    }
+}
+static int CompareWorlds(FuseWorld &a, FuseWorld &b) {
+    int bad = 0;
+    for (int i = 0; i < a.K.N; i++) bad += a.Id(a.K.mvpMapPoints[i]) != b.Id(b.K.mvpMapPoints[i]);
+    for (int i = 0; i < a.K2.N; i++) bad += a.Id(a.K2.mvpMapPoints[i]) != b.Id(b.K2.mvpMapPoints[i]);
+    vector<MapPoint *> ia(a.id.size()), ib(b.id.size());
+    for (auto &kv : a.id) ia[kv.second] = kv.first;
+    for (auto &kv : b.id) ib[kv.second] = kv.first;
+    if (ia.size() != ib.size()) return 1 << 20;
+    for (size_t k = 0; k < ia.size(); k++) {
+        MapPoint *p = ia[k], *q = ib[k];
+        bad += p->mbBad != q->mbBad; bad += p->nObs != q->nObs; bad += a.Id(p->mpReplaced) != b.Id(q->mpReplaced);
+        bad += p->mObservations.size() != q->mObservations.size();
+        bad += p->GetIndexInKeyFrame(&a.K) != q->GetIndexInKeyFrame(&b.K);
+        bad += p->GetIndexInKeyFrame(&a.K2) != q->GetIndexInKeyFrame(&b.K2);
+        bad += p->mnFound != q->mnFound;
+    }
+    return bad;
+}
+
+static void TestFuse() {
+    vector<Desc> lm(2500); for (auto &d : lm) d = RandDesc();
+    Raw rc = MakeRaw(1500, lm, 0, 1500, 10, 0.5, 0.5, 0.04, 0.0);
+    const int Q = 2500;
+    for (int variant = 0; variant < 2; variant++) for (float th : {3.0f, 6.0f}) {
+        auto saved = rng;
+        FuseWorld a; BuildFuseWorld(a, rc, lm, Q, variant == 0);
+        rng = saved;
+        FuseWorld b; BuildFuseWorld(b, rc, lm, Q, variant == 0);
+        // expected: flat queries -> oracle -> the reference's loop on copy b
+        FlatQ q(Q);
+        std::set<MapPoint *> found = b.K.GetMapPoints();
+        for (int i = 0; i < Q; i++) {
+            MapPoint *p = b.pts[i];
+            if (!p) continue;
+            if (variant == 0 ? (p->mbBad || p->IsInKeyFrame(&b.K)) : (p->mbBad || found.count(p) != 0)) continue;
+            q.Set(i, p, rc, th, true);
+        }
+        orbm_frame_view vk = rc.view(true);
+        orbm_win_queries wq = q.view();
+        vector<int32_t> best(Q); uint64_t nc;
+        orc_search_window_free(&vk, &wq, 50, variant == 0, best.data(), &nc);
+        int want = 0, nrepl = 0, nadd = 0;
+        vector<int> wantReplace(Q, -1);
+        for (int i = 0; i < Q; i++) {
+            MapPoint *pMP = b.pts[i];
+            if (!pMP) continue;
+            if (variant == 0) { if (pMP->isBad() || pMP->IsInKeyFrame(&b.K)) continue; }
+            if (best[i] < 0) continue;
+            MapPoint *in = b.K.GetMapPoint(best[i]);
+            if (in) {
+                if (!in->isBad()) {
+                    if (variant == 1) wantReplace[i] = b.Id(in);
+                    else if (in->Observations() > pMP->Observations()) pMP->Replace(in);
+                    else in->Replace(pMP);
+                    nrepl++;
+                }
+            } else { pMP->AddObservation(&b.K, best[i]); b.K.AddMapPoint(pMP, best[i]); nadd++; }
+            want++;
+        }
+        ORBmatcher matcher(0.6f, true);
+        int cnt;
+        vector<MapPoint *> repl(Q, nullptr);
+        if (variant == 0) cnt = matcher.Fuse(&a.K, a.pts, th);
+        else {
+            cv::Mat Scw = cv::Mat::eye(4, 4, CV_32F);
+            for (int k = 0; k < 3; k++) Scw.at<float>(k, k) = 2.0f;      // scale 2: Rcw = I, tcw = 0 exactly
+            cnt = matcher.Fuse(&a.K, Scw, a.pts, th, repl);
+        }
+        EXPECT(cnt == want, "fuse variant %d th %.0f: count %d vs %d", variant, th, cnt, want);
+        int bad = CompareWorlds(a, b);
+        EXPECT(bad == 0, "fuse variant %d th %.0f: %d state mismatches", variant, th, bad);
+        if (variant == 1) { int br = 0; for (int i = 0; i < Q; i++) br += a.Id(repl[i]) != wantReplace[i]; EXPECT(br == 0, "fuse replace list: %d mismatches", br); }
+        EXPECT(nrepl > 40 && nadd > 40, "fuse variant %d: too few events (%d replace, %d add)", variant, nrepl, nadd);
+    }
+    printf("Fuse x2 done\n");
+}
+
 int main() {
     try {
         // a1 helper
@@ -402,6 +605,8 @@ int main() {
         TestTriang();
         TestProjPoints();
         TestWindowOverloads();
+        TestSim3();
+        TestFuse();
     } catch (const std::exception &e) {
         printf("EXCEPTION: %s\n", e.what());
         return 2;
