@@ -121,6 +121,8 @@ __global__ void window_kernel(WinParams P) {
     int *hist = (int *)(base + 5 * (size_t)n);
     int *nmatch = hist + 32;
     int *keep = hist + 33;
+    int *bucket = hist + 64;                                    // 32 cost classes
+    uint16_t *perm = reinterpret_cast<uint16_t *>(hist + 96);   // blockDim entries
 
     // query source
     const QSetDev *QS = nullptr;
@@ -151,18 +153,22 @@ __global__ void window_kernel(WinParams P) {
     const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
 
-    // one query per lane; the NEXT chunk's query is loaded while the current chunk is matched
+    // One query per lane.  Window areas differ by more than 10x between pyramid levels and a wave costs what its
+    // widest window costs, so the lane -> query assignment inside a chunk is sorted by window size (counting sort
+    // over 32 classes of covered grid cells).  Claim priority stays the query's index (`ql`, chunk-local), so the
+    // result is the sequential one whatever the assignment.  The NEXT chunk is sorted and loaded while the current
+    // one is matched.
     struct Query {
         uint4 d0, d1;
         float x, y, r, xr, angle;
-        int minL, maxL;
+        int minL, maxL, ql;
         uint32_t flags;
         bool valid;
     };
-    auto load_query = [&](int qi) {
+    auto load_params = [&](int qi) {
         Query q;
         q.d0 = q.d1 = make_uint4(0, 0, 0, 0);
-        q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.flags = 0; q.valid = false;
+        q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.ql = 0; q.flags = 0; q.valid = false;
         if (qi >= Q) return q;
         if (MODE == MODE_INIT) {
             if (F1->octave[qi] == 0) {                                                    // :582-584
@@ -190,19 +196,53 @@ __global__ void window_kernel(WinParams P) {
                 }
             }
         }
+        return q;
+    };
+    auto load_query = [&](int qbase, int ql) {
+        Query q = load_params(qbase + ql);
+        q.ql = ql;
         if (q.valid) {
             const uint32_t *dsrc = MODE == MODE_INIT ? F1->desc : QS->desc;
-            const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)(qbase + ql);
             q.d0 = p4[0]; q.d1 = p4[1];
         }
         return q;
     };
+    // cost class of a query = grid cells its window covers / 4 (0 = nothing to do)
+    auto cost_class = [&](const Query &q) {
+        if (!q.valid) return 0;
+        const float xr_ = __fsub_rn(q.x, acc.min_x), yr_ = __fsub_rn(q.y, acc.min_y);
+        const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr_, q.r), acc.inv_w)));
+        const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr_, q.r), acc.inv_w)));
+        const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr_, q.r), acc.inv_h)));
+        const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr_, q.r), acc.inv_h)));
+        if (x1 < x0 || y1 < y0) return 0;
+        return min(31, 1 + ((x1 - x0 + 1) * (y1 - y0 + 1) >> 2));
+    };
+    // returns the chunk-local index of the query this lane takes (widest windows first)
+    auto assign_lane = [&](int cls) {
+        if (MODE == MODE_INIT) return tid;           // one radius for all queries (:587): nothing to balance
+        if (tid < 32) bucket[tid] = 0;
+        __syncthreads();
+        const int rank = atomicAdd(&bucket[cls], 1);
+        __syncthreads();
+        int start = 0;
+        for (int b = 31; b > cls; b--) start += bucket[b];
+        perm[start + rank] = (uint16_t)tid;
+        __syncthreads();
+        return (int)perm[tid];
+    };
 
-    Query nextq = load_query(tid);
+    Query pnext = load_params(tid);
+    Query nextq = load_query(0, assign_lane(cost_class(pnext)));
+    pnext = load_params(nthr + tid);
     for (int base_q = 0; base_q < Q; base_q += nthr) {
-        const int qi = base_q + tid;
         const Query cur = nextq;
-        nextq = load_query(qi + nthr);
+        const int ql = cur.ql, qi = base_q + ql;
+        if (base_q + nthr < Q) {
+            nextq = load_query(base_q + nthr, assign_lane(cost_class(pnext)));
+            pnext = load_params(base_q + 2 * nthr + tid);
+        }
         bool unresolved = cur.valid;
         const uint32_t qd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
         const float x = cur.x, y = cur.y, r = cur.r, xr = cur.xr, qangle = cur.angle;
@@ -260,7 +300,7 @@ __global__ void window_kernel(WinParams P) {
                     if (st & ORBM_MP_PRESENT) return;                                      // :2048 / :512
                 }
                 if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                    // :608
-                if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                       // this query may still claim k
+                if (dist <= thr) atomicMin(&post[k], (uint32_t)ql);                       // this query may still claim k
                 if (dist < bestDist) {
                     bestDist2 = bestDist; bestDist = dist;
                     bestLevel2 = bestLevel; bestLevel = oct;
@@ -301,12 +341,12 @@ __global__ void window_kernel(WinParams P) {
                 if (cached) {
                     for (int i = 0; i < wave_ncand; i++) {
                         const uint32_t v = cc[i];
-                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)tid) is_final = false;
+                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)ql) is_final = false;
                     }
                 } else {
                     auto chk = [&](int k, int oct, float) {
                         if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
-                        if (post[k] < (uint32_t)tid) is_final = false;
+                        if (post[k] < (uint32_t)ql) is_final = false;
                     };
                     if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, chk);
                     else walk_window<false>(acc, x, y, r, minL, maxL, chk);
@@ -409,7 +449,7 @@ __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_i
     const FrameDev &F = P.frames[P.frame_ids[inst]];
     const QSetDev &QS = P.qsets[P.qset_ids[inst]];
     const int qi = chunk * 256 + (int)threadIdx.x;
-    if (qi >= QS.n) return;
+    if (qi >= QS.n || qi >= P.stride) return;
     int32_t *out = P.out + (size_t)inst * P.stride;
     int result = -1;
     if (QS.flags[qi] & ORBM_Q_VALID) {
@@ -448,11 +488,11 @@ __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_i
     out[qi] = result;
 }
 
-constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint <= 160 KB
+constexpr int WIN_LDS_FRAME_MAX_N = 2160;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint + lane assignment <= 160 KB
 
 template <int MODE, bool LDS_FRAME>
 int launch_mode2(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
-    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64) * 4;
+    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 96 + 512) * 4;
     if (lds > 48 * 1024) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
