@@ -90,8 +90,186 @@ __device__ __forceinline__ void walk_window(const FrameAcc &f, float x, float y,
 
 constexpr int WIN_CACHE = 16;  // candidates remembered per query (registers); wider windows fall back to re-walking
 
-template <int MODE, bool LDS_FRAME>
-__global__ void window_kernel(WinParams P) {
+struct Query {
+    uint4 d0, d1;
+    float x, y, r, xr, angle;
+    int minL, maxL, ql;
+    uint32_t flags;
+    bool valid;
+};
+
+// where an instance's queries come from: a query set, or (MODE_INIT) the keypoints of frame 1
+struct QSrc {
+    const QSetDev *QS;
+    const FrameDev *F1;
+    int Q;
+};
+
+template <int MODE>
+__device__ __forceinline__ QSrc query_source(const WinParams &P, int inst) {
+    QSrc S;
+    S.QS = nullptr; S.F1 = nullptr;
+    if (MODE == MODE_INIT) { S.F1 = &P.frames[P.qset_ids[inst]]; S.Q = S.F1->n; }
+    else { S.QS = &P.qsets[P.qset_ids[inst]]; S.Q = S.QS->n; }
+    return S;
+}
+
+// everything of query qi except its descriptor (F = the frame searched)
+template <int MODE>
+__device__ __forceinline__ Query load_params(const WinParams &P, const FrameDev &F, const QSrc &S, int qi) {
+    Query q;
+    q.d0 = q.d1 = make_uint4(0, 0, 0, 0);
+    q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.ql = 0; q.flags = 0; q.valid = false;
+    if (qi >= S.Q) return q;
+    if (MODE == MODE_INIT) {
+        if (S.F1->octave[qi] == 0) {                                                  // :582-584
+            q.valid = true;
+            q.x = P.prev_xy[2 * qi]; q.y = P.prev_xy[2 * qi + 1];
+            q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
+            q.angle = S.F1->angle[qi];
+        }
+    } else {
+        const QSetDev *QS = S.QS;
+        q.flags = QS->flags[qi];
+        if (q.flags & ORBM_Q_VALID) {
+            q.valid = true;
+            q.x = QS->f0[qi]; q.y = QS->f1[qi];
+            if (MODE == MODE_PROJ) {
+                const int lvl = QS->l0[qi];
+                float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
+                if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                          // :61, :84-85
+                q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
+                q.minL = lvl - 1; q.maxL = lvl;
+                q.xr = QS->f2[qi];
+            } else {
+                q.r = QS->f2[qi]; q.minL = QS->l0[qi]; q.maxL = QS->l1[qi];
+                if (QS->f3) q.xr = QS->f3[qi];
+                if (QS->angle) q.angle = QS->angle[qi];
+            }
+        }
+    }
+    return q;
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_desc(const QSrc &S, int qi, Query &q) {
+    const uint32_t *dsrc = MODE == MODE_INIT ? S.F1->desc : S.QS->desc;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
+    q.d0 = p4[0]; q.d1 = p4[1];
+}
+
+// the gates of the reference's inner loop that do not depend on the slot state
+template <int MODE>
+__device__ __forceinline__ bool static_gates(const Query &q, bool stereo_gate, int oct, float ur) {
+    if (MODE == MODE_SIM3) { if (oct < q.minL || oct > q.maxL) return false; }        // :515-518
+    if (stereo_gate) {
+        if (ur > 0) {
+            const float er = fabsf(__fsub_rn(q.xr, ur));
+            if (er > q.r) return false;                                                // :117-122 / :1883-1891
+        }
+    }
+    return true;
+}
+
+template <int MODE>
+__device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
+    return MODE == MODE_PROJ || (MODE == MODE_LAST && S.QS->f3 != nullptr);
+}
+
+// ---- split form, kernel 1 of 2: ONE window walk per query, anywhere on the chip.  Nothing here depends on the slot
+// state, so queries are independent.  A workgroup stages the frame's grid and cell-ordered records in LDS once and
+// its waves then take rows of 64 queries (one per lane) with no barrier between them.  Per lane: a single flat loop
+// over the window's records (column changes are just another iteration, so a wave iterates max-over-lanes of the
+// window's size, not the sum over columns of the widest column run), branch-free gates, survivors parked in LDS;
+// then a second, wave-uniform loop computes the Hamming distances.  Each candidate that passes the static gates is
+// stored as k | oct << 16 | dist << 20 in reference visit order, in rows of 64 lanes (row i of a wave = candidate i
+// of its 64 queries; only rows some lane needs are written).
+constexpr int COLLECT_THREADS = 512;
+
+template <int MODE>
+__global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
+                                                                  uint32_t *cand, uint8_t *ncand_out) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
+    const int tid = threadIdx.x;
+    const FrameDev &F = P.frames[P.frame_ids[inst]];
+    const int n = F.n;
+    uint32_t *l_cell = lds;                                                      // 3076
+    float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);                      // 4n
+    uint32_t *l_cc = lds + 3076 + 4 * (size_t)n;                                 // WIN_CACHE x COLLECT_THREADS
+    for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
+    for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
+    __syncthreads();
+    const QSrc S = query_source<MODE>(P, inst);
+    const bool stereo_gate = has_stereo_gate<MODE>(S);
+    const uint4 *gdesc = reinterpret_cast<const uint4 *>(F.desc);
+    const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
+    constexpr int WAVES = COLLECT_THREADS / 64;
+    const int lane = tid & 63;
+    for (int rowi = part * WAVES + (tid >> 6); rowi < waves_per_inst; rowi += wgs_per_inst * WAVES) {
+        const int qi = rowi * 64 + lane;
+        Query q = load_params<MODE>(P, F, S, qi);
+        if (q.valid) load_desc<MODE>(S, qi, q);
+        int ncand = 0;
+        if (q.valid) {
+            // Frame.cc:434-498 / KeyFrame.cc:766-812, as walk_window()
+            const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
+            const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
+            const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
+            const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
+            const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
+            const bool empty = x0 >= ORBM_GRID_COLS || x1 < 0 || y0 >= ORBM_GRID_ROWS || y1 < 0;
+            // level gates: Frame's GetFeaturesInArea filters when minLevel > 0 or maxLevel >= 0 (a negative maxLevel
+            // leaves the top open); KeyFrame's does not filter, SearchByProjection(KF, Scw, ...) does it itself (:515-518)
+            int lo = -1, hi = 255;
+            if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
+            else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+            int ix = x0 - 1;
+            uint32_t j = 0, e = 0;
+            if (!empty)
+                for (;;) {
+                    if (j >= e) {                                  // next column: one contiguous run of records
+                        if (++ix > x1) break;
+                        j = l_cell[ix * ORBM_GRID_ROWS + y0];
+                        e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
+                        continue;
+                    }
+                    const float4 rc = l_rec[j++];
+                    const uint32_t w = __float_as_uint(rc.w);
+                    const int oct = (int)(w >> 16);
+                    int pass = (int)(oct >= lo) & (int)(oct <= hi) & (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
+                    if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
+                    if (pass) {
+                        if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = w;
+                        ncand++;
+                    }
+                }
+        }
+        int wave_ncand = min(ncand, WIN_CACHE);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
+        wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
+        const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
+        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + lane;
+        for (int i = 0; i < wave_ncand; i++) {
+            uint32_t v = 0;
+            if (i < ncand) {
+                v = l_cc[i * COLLECT_THREADS + tid];
+                const int k = (int)(v & 0xFFFFu);
+                const uint4 dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
+                const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
+                v |= hamming256(qd, cd) << 20;
+            }
+            row[i * 64] = v;
+        }
+        ncand_out[(size_t)inst * waves_per_inst * 64 + qi] = (uint8_t)min(ncand, 255);
+    }
+}
+
+// ---- the claim loop.  PRE = false: collects inline (one kernel does everything; frame optionally staged in LDS).
+// PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
+template <int MODE, bool LDS_FRAME, bool PRE>
+__global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *cand, const uint8_t *ncand_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameDev &F = P.frames[P.frame_ids[inst]];
@@ -121,15 +299,11 @@ __global__ void window_kernel(WinParams P) {
     int *hist = (int *)(base + 5 * (size_t)n);
     int *nmatch = hist + 32;
     int *keep = hist + 33;
-    int *bucket = hist + 64;                                    // 32 cost classes
-    uint16_t *perm = reinterpret_cast<uint16_t *>(hist + 96);   // blockDim entries
 
-    // query source
-    const QSetDev *QS = nullptr;
-    const FrameDev *F1 = nullptr;
-    int Q;
-    if (MODE == MODE_INIT) { F1 = &P.frames[P.qset_ids[inst]]; Q = F1->n; }
-    else { QS = &P.qsets[P.qset_ids[inst]]; Q = QS->n; }
+    const QSrc S = query_source<MODE>(P, inst);
+    const QSetDev *QS = S.QS;
+    const FrameDev *F1 = S.F1;
+    const int Q = S.Q;
     int32_t *out = P.out + (size_t)inst * P.stride;
 
     for (int i = tid; i < n; i += nthr) {
@@ -148,104 +322,36 @@ __global__ void window_kernel(WinParams P) {
 
     const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
                           (MODE == MODE_INIT || QS->angle != nullptr);
-    const bool bFactor = P.th != 1.0f;                                                     // :61
-    const bool stereo_gate = MODE == MODE_PROJ || (MODE == MODE_LAST && QS->f3 != nullptr);
+    const bool stereo_gate = has_stereo_gate<MODE>(S);
     const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
+    const uint8_t *nc_in = PRE ? ncand_in + (size_t)inst * waves_per_inst * 64 : nullptr;
+    const uint32_t *rows = PRE ? cand + (size_t)inst * waves_per_inst * (WIN_CACHE * 64) : nullptr;
 
-    // One query per lane.  Window areas differ by more than 10x between pyramid levels and a wave costs what its
-    // widest window costs, so the lane -> query assignment inside a chunk is sorted by window size (counting sort
-    // over 32 classes of covered grid cells).  Claim priority stays the query's index (`ql`, chunk-local), so the
-    // result is the sequential one whatever the assignment.  The NEXT chunk is sorted and loaded while the current
-    // one is matched.
-    struct Query {
-        uint4 d0, d1;
-        float x, y, r, xr, angle;
-        int minL, maxL, ql;
-        uint32_t flags;
-        bool valid;
-    };
-    auto load_params = [&](int qi) {
-        Query q;
-        q.d0 = q.d1 = make_uint4(0, 0, 0, 0);
-        q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.ql = 0; q.flags = 0; q.valid = false;
-        if (qi >= Q) return q;
-        if (MODE == MODE_INIT) {
-            if (F1->octave[qi] == 0) {                                                    // :582-584
-                q.valid = true;
-                q.x = P.prev_xy[2 * qi]; q.y = P.prev_xy[2 * qi + 1];
-                q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
-                q.angle = F1->angle[qi];
-            }
-        } else {
-            q.flags = QS->flags[qi];
-            if (q.flags & ORBM_Q_VALID) {
-                q.valid = true;
-                q.x = QS->f0[qi]; q.y = QS->f1[qi];
-                if (MODE == MODE_PROJ) {
-                    const int lvl = QS->l0[qi];
-                    float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
-                    if (bFactor) rv = __fmul_rn(rv, P.th);                               // :84-85
-                    q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
-                    q.minL = lvl - 1; q.maxL = lvl;
-                    q.xr = QS->f2[qi];
-                } else {
-                    q.r = QS->f2[qi]; q.minL = QS->l0[qi]; q.maxL = QS->l1[qi];
-                    if (QS->f3) q.xr = QS->f3[qi];
-                    if (QS->angle) q.angle = QS->angle[qi];
-                }
-            }
+    // one query per lane (claim priority = the query's index); the NEXT chunk's query is loaded while the current
+    // chunk is matched
+    auto load_query = [&](int qi, int &nc) {
+        Query q = load_params<MODE>(P, F, S, qi);
+        nc = 0;
+        if (PRE) {
+            if (qi < Q) nc = nc_in[qi];
+            if (nc > WIN_CACHE) load_desc<MODE>(S, qi, q);     // only the re-walking fallback compares descriptors here
+        } else if (q.valid) {
+            load_desc<MODE>(S, qi, q);
         }
         return q;
     };
-    auto load_query = [&](int qbase, int ql) {
-        Query q = load_params(qbase + ql);
-        q.ql = ql;
-        if (q.valid) {
-            const uint32_t *dsrc = MODE == MODE_INIT ? F1->desc : QS->desc;
-            const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)(qbase + ql);
-            q.d0 = p4[0]; q.d1 = p4[1];
-        }
-        return q;
-    };
-    // cost class of a query = grid cells its window covers / 4 (0 = nothing to do)
-    auto cost_class = [&](const Query &q) {
-        if (!q.valid) return 0;
-        const float xr_ = __fsub_rn(q.x, acc.min_x), yr_ = __fsub_rn(q.y, acc.min_y);
-        const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr_, q.r), acc.inv_w)));
-        const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr_, q.r), acc.inv_w)));
-        const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr_, q.r), acc.inv_h)));
-        const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr_, q.r), acc.inv_h)));
-        if (x1 < x0 || y1 < y0) return 0;
-        return min(31, 1 + ((x1 - x0 + 1) * (y1 - y0 + 1) >> 2));
-    };
-    // returns the chunk-local index of the query this lane takes (widest windows first)
-    auto assign_lane = [&](int cls) {
-        if (MODE == MODE_INIT) return tid;           // one radius for all queries (:587): nothing to balance
-        if (tid < 32) bucket[tid] = 0;
-        __syncthreads();
-        const int rank = atomicAdd(&bucket[cls], 1);
-        __syncthreads();
-        int start = 0;
-        for (int b = 31; b > cls; b--) start += bucket[b];
-        perm[start + rank] = (uint16_t)tid;
-        __syncthreads();
-        return (int)perm[tid];
-    };
 
-    Query pnext = load_params(tid);
-    Query nextq = load_query(0, assign_lane(cost_class(pnext)));
-    pnext = load_params(nthr + tid);
+    int nc_next = 0;
+    Query nextq = load_query(tid, nc_next);
     for (int base_q = 0; base_q < Q; base_q += nthr) {
+        const int qi = base_q + tid;
         const Query cur = nextq;
-        const int ql = cur.ql, qi = base_q + ql;
-        if (base_q + nthr < Q) {
-            nextq = load_query(base_q + nthr, assign_lane(cost_class(pnext)));
-            pnext = load_params(base_q + 2 * nthr + tid);
-        }
+        const int nc_cur = nc_next;
+        nextq = load_query(qi + nthr, nc_next);
         bool unresolved = cur.valid;
         const uint32_t qd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
-        const float x = cur.x, y = cur.y, r = cur.r, xr = cur.xr, qangle = cur.angle;
+        const float x = cur.x, y = cur.y, r = cur.r, qangle = cur.angle;
         const int minL = cur.minL, maxL = cur.maxL;
         const uint32_t qflags = cur.flags;
 
@@ -257,15 +363,11 @@ __global__ void window_kernel(WinParams P) {
         uint32_t cc[WIN_CACHE];
 #pragma unroll
         for (int i = 0; i < WIN_CACHE; i++) cc[i] = 0;
-        if (unresolved) {
+        if (PRE) {
+            ncand = nc_cur;
+        } else if (unresolved) {
             auto collect = [&](int k, int oct, float ur) {
-                if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }          // :515-518
-                if (stereo_gate) {
-                    if (ur > 0) {
-                        const float er = fabsf(__fsub_rn(xr, ur));
-                        if (er > r) return;                                                // :117-122 / :1883-1891
-                    }
-                }
+                if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                 if (ncand < WIN_CACHE) {
                     const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                     const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -277,13 +379,18 @@ __global__ void window_kernel(WinParams P) {
             };
             if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, collect);
             else walk_window<false>(acc, x, y, r, minL, maxL, collect);
-            if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
         }
+        if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
         const bool cached = ncand <= WIN_CACHE;
         int wave_ncand = min(ncand, WIN_CACHE);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
         wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
+        if (PRE) {
+            const uint32_t *row = rows + (size_t)(qi >> 6) * (WIN_CACHE * 64) + (qi & 63);
+#pragma unroll
+            for (int i = 0; i < WIN_CACHE; i++) if (i < wave_ncand) cc[i] = row[i * 64];
+        }
 
         int round = 0;
         while (true) {
@@ -300,7 +407,7 @@ __global__ void window_kernel(WinParams P) {
                     if (st & ORBM_MP_PRESENT) return;                                      // :2048 / :512
                 }
                 if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                    // :608
-                if (dist <= thr) atomicMin(&post[k], (uint32_t)ql);                       // this query may still claim k
+                if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                       // this query may still claim k
                 if (dist < bestDist) {
                     bestDist2 = bestDist; bestDist = dist;
                     bestLevel2 = bestLevel; bestLevel = oct;
@@ -319,13 +426,7 @@ __global__ void window_kernel(WinParams P) {
                     }
                 } else {
                     auto body = [&](int k, int oct, float ur) {
-                        if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
-                        if (stereo_gate) {
-                            if (ur > 0) {
-                                const float er = fabsf(__fsub_rn(xr, ur));
-                                if (er > r) return;
-                            }
-                        }
+                        if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                         const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                         const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                         consider(k, oct, (int)hamming256(qd, cd));
@@ -341,12 +442,12 @@ __global__ void window_kernel(WinParams P) {
                 if (cached) {
                     for (int i = 0; i < wave_ncand; i++) {
                         const uint32_t v = cc[i];
-                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)ql) is_final = false;
+                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)tid) is_final = false;
                     }
                 } else {
                     auto chk = [&](int k, int oct, float) {
                         if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
-                        if (post[k] < (uint32_t)ql) is_final = false;
+                        if (post[k] < (uint32_t)tid) is_final = false;
                     };
                     if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, chk);
                     else walk_window<false>(acc, x, y, r, minL, maxL, chk);
@@ -488,37 +589,68 @@ __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_i
     out[qi] = result;
 }
 
-constexpr int WIN_LDS_FRAME_MAX_N = 2160;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint + lane assignment <= 160 KB
+constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B descriptors + 20 B state per keypoint <= 160 KB
 
-template <int MODE, bool LDS_FRAME>
-int launch_mode2(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
-    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 96 + 512) * 4;
+template <int MODE, bool LDS_FRAME, bool PRE>
+int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
+                  const uint32_t *cand, const uint8_t *ncand) {
+    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64) * 4;
     if (lds > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME>),
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME, PRE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME>), dim3(n_inst), dim3(threads), lds, ctx->stream, P);
+    hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
+                       waves_per_inst, cand, ncand);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
 
-int g_win_force_global = 0;   // tuning / test knob: 1 = never stage the frame in LDS
+// tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
+// 2 = single kernel reading the frame from global memory
+int g_win_variant = 0;
 
 template <int MODE>
-int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads) {
-    // the whole frame (grid, records, descriptors) fits one CU's LDS up to 2200 keypoints: 1024-thread workgroup
-    if (max_n <= WIN_LDS_FRAME_MAX_N && !g_win_force_global) return launch_mode2<MODE, true>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024);
-    return launch_mode2<MODE, false>(ctx, P, n_inst, max_n, threads);
+int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
+    // MODE_INIT: one window size, hundreds of candidates; frames too large for collect_kernel's LDS staging
+    const bool single = MODE == MODE_INIT || g_win_variant != 0 ||
+                        (3076 + 4 * (size_t)max_n + (size_t)WIN_CACHE * COLLECT_THREADS) * 4 > 160 * 1024;
+    if (single) {
+        if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
+            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr);
+        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr);
+    }
+    if (MODE != MODE_INIT) {
+        const int waves_per_inst = (max_q + 63) / 64;
+        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr);
+        const size_t rows = (size_t)n_inst * waves_per_inst;
+        const size_t cand_bytes = rows * WIN_CACHE * 64 * 4;
+        int rc = orbm_ws2_reserve(ctx, cand_bytes + rows * 64 + 256);
+        if (rc) return rc;
+        uint32_t *cand = (uint32_t *)ctx->ws2;
+        uint8_t *ncand = (uint8_t *)ctx->ws2 + cand_bytes;
+        // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
+        constexpr int WAVES = COLLECT_THREADS / 64;
+        int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
+        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)WIN_CACHE * COLLECT_THREADS) * 4;
+        if (lds > 48 * 1024)
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
+                           waves_per_inst, wgs_per_inst, cand, ncand);
+        HIPCHK(ctx, hipGetLastError());
+        const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
+        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand);
+    }
+    return ORBM_OK;
 }
 
-int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n) {
-    const int threads = 512;
+int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n, int max_q) {
     switch (mode) {
-        case MODE_LAST: return launch_mode<MODE_LAST>(ctx, P, n_inst, max_n, threads);
-        case MODE_KF: return launch_mode<MODE_KF>(ctx, P, n_inst, max_n, threads);
-        case MODE_SIM3: return launch_mode<MODE_SIM3>(ctx, P, n_inst, max_n, threads);
-        case MODE_INIT: return launch_mode<MODE_INIT>(ctx, P, n_inst, max_n, 256);
-        default: return launch_mode<MODE_PROJ>(ctx, P, n_inst, max_n, threads);
+        case MODE_LAST: return launch_mode<MODE_LAST>(ctx, P, n_inst, max_n, max_q);
+        case MODE_KF: return launch_mode<MODE_KF>(ctx, P, n_inst, max_n, max_q);
+        case MODE_SIM3: return launch_mode<MODE_SIM3>(ctx, P, n_inst, max_n, max_q);
+        case MODE_INIT: return launch_mode<MODE_INIT>(ctx, P, n_inst, max_n, max_q);
+        default: return launch_mode<MODE_PROJ>(ctx, P, n_inst, max_n, max_q);
     }
 }
 
@@ -530,15 +662,21 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
         return orbm_fail(ctx, ORBM_EINVAL, "%s: null argument or negative size", who);
     if (n_inst == 0) return ORBM_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int max_n = 0;
+    int max_n = 0, max_q = 0;
     if (!io_on_device) {
         int rc = orbm_check_frames(ctx, n_inst, frame, "frame");
         if (!rc) rc = orbm_check_qsets(ctx, n_inst, qset, mode == MODE_PROJ ? 0 : 1, "qset");
         if (rc) return rc;
-        for (int k = 0; k < n_inst; k++) max_n = std::max(max_n, ctx->h_frames[frame[k]].n);
+        for (int k = 0; k < n_inst; k++) {
+            max_n = std::max(max_n, ctx->h_frames[frame[k]].n);
+            max_q = std::max(max_q, ctx->h_qsets[qset[k]].n);
+        }
         if (max_n > stride) return orbm_fail(ctx, ORBM_EINVAL, "%s: stride %d < largest frame %d", who, stride, max_n);
     } else {
         max_n = stride;  // the caller's stride bounds every frame of the batch
+        // the ids live on the device: bound the query count by the largest live query set of the context
+        for (size_t k = 0; k < ctx->h_qsets.size(); k++)
+            if (ctx->qset_arena[k] >= 0) max_q = std::max(max_q, ctx->h_qsets[k].n);
     }
     if (max_n > WIN_MAX_N)
         return orbm_fail(ctx, ORBM_ELIMIT, "%s: frames of more than %d keypoints are not supported by the windowed kernels (got %d)", who, WIN_MAX_N, max_n);
@@ -562,15 +700,15 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
     P.slot_flags = (const uint8_t *)dsf;
     P.out = (int32_t *)down; P.counts = (int32_t *)dc;
     P.th = th; P.ratio = ratio; P.dist_th = dist_th; P.check_ori = check_ori; P.stride = stride;
-    rc = launch_window(ctx, mode, P, n_inst, std::max(max_n, 1));
+    rc = launch_window(ctx, mode, P, n_inst, std::max(max_n, 1), max_q);
     if (rc) return rc;
     return io.finish();
 }
 
 }  // namespace
 
-// tuning / test knob (not part of the public ABI): 1 = keep the frame in global memory even when it fits LDS
-extern "C" void orbm__window_force_global(int v) { g_win_force_global = v; }
+// tuning / test knob (not part of the public ABI): see g_win_variant
+extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
 
 extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
                                              float th, float ratio, const uint8_t *slot_flags, int32_t stride,
@@ -614,7 +752,7 @@ extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, f
     P.frame_ids = d_ids; P.qset_ids = d_ids + 1;
     P.prev_xy = d_prev; P.out = d_m12; P.counts = d_count;
     P.th = 1.0f; P.ratio = ratio; P.dist_th = ORBM_TH_LOW; P.check_ori = check_ori; P.stride = n1; P.window = window;
-    rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1));
+    rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1), n1);
     if (rc) return rc;
     int32_t count = 0;
     HIPCHK(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));

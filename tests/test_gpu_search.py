@@ -207,27 +207,30 @@ def test_search_init_steals(ctx, orc):
     ctx.free_frames(ids)
 
 
-def test_window_global_memory_path_still_exact(ctx, orc):
-    """Frames above 2200 keypoints (and the force-global knob) use the kernel variant that reads the frame from
-    global memory instead of LDS: same results."""
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
+    """The windowed searches have three forms (split collect + claims = default, single kernel with the frame in LDS,
+    single kernel reading global memory; frames above 2200 keypoints never use LDS staging): same results."""
     from orbslam2_amd import _lib
-    f, q = synth.proj_instance(seed=901, n=3000, n_queries=8000, claimed_frac=0.1, obs_frac=0.7)
-    fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
-    counts, owner = ctx.search_proj_points(fid, qid, 3.0, 0.8, stride=3000)
-    wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8)
-    assert counts[0] == wc and np.array_equal(owner[0], wo)
-    ctx.free_frames(fid); ctx.free_queries(qid)
     L = _lib.load()
     try:
-        L.orbm__window_force_global(1)
-        f, q = synth.proj_instance(seed=902, n=800, n_queries=5000, stereo=True, obs_frac=0.6)
-        fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
-        counts, owner = ctx.search_proj_points(fid, qid, 5.0, 0.8, stride=800)
-        wc, wo, _ = orc.search_proj_points(f, q, 5.0, 0.8)
-        assert counts[0] == wc and np.array_equal(owner[0], wo)
-        ctx.free_frames(fid); ctx.free_queries(qid)
+        L.orbm__window_variant(variant)
+        for seed, n, nq, th, stereo in ((901, 3000, 8000, 3.0, False), (902, 800, 5000, 5.0, True), (904, 2000, 3000, 1.0, False)):
+            f, q = synth.proj_instance(seed=seed, n=n, n_queries=nq, claimed_frac=0.1, obs_frac=0.7, stereo=stereo)
+            fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+            counts, owner = ctx.search_proj_points(fid, qid, th, 0.8, stride=n)
+            wc, wo, _ = orc.search_proj_points(f, q, th, 0.8)
+            assert counts[0] == wc and np.array_equal(owner[0], wo), (seed, variant)
+            ctx.free_frames(fid); ctx.free_queries(qid)
+        for mode in (0, 1, 2):
+            f, q = synth.window_instance(960 + mode, mode, n=1500, n_queries=2500, stereo=(mode == 0), th=7.0)
+            fid = ctx.upload_frames([f]); qid = ctx.upload_win_queries([q])
+            counts, owner = ctx.search_window(mode, fid, qid, 100 if mode < 2 else 50, mode < 2, stride=1500)
+            wc, wo, _ = orc.search_window(mode, f, q, 100 if mode < 2 else 50, mode < 2)
+            assert counts[0] == wc and np.array_equal(owner[0], wo), (mode, variant)
+            ctx.free_frames(fid); ctx.free_queries(qid)
     finally:
-        L.orbm__window_force_global(0)
+        L.orbm__window_variant(0)
 
 
 def test_frames_over_the_window_limit_are_rejected(ctx):
