@@ -88,6 +88,7 @@ __device__ __forceinline__ void walk_window(const FrameAcc &f, float x, float y,
     }
 }
 
+constexpr int SCAN_U = 8;      // split form: queries scanned for liveness per lane and pass
 constexpr int WIN_CACHE = 16;  // candidates remembered per query (registers); wider windows fall back to re-walking
 
 struct Query {
@@ -188,7 +189,7 @@ constexpr int COLLECT_THREADS = 512;
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  uint32_t *cand, uint8_t *ncand_out) {
+                                                                  uint32_t *cand, uint8_t *ncand_out, uint64_t *postable_out) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
     const int tid = threadIdx.x;
@@ -197,6 +198,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     uint32_t *l_cell = lds;                                                      // 3076
     float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);                      // 4n
     uint32_t *l_cc = lds + 3076 + 4 * (size_t)n;                                 // WIN_CACHE x COLLECT_THREADS
+    int *l_bucket = (int *)(l_cc + WIN_CACHE * COLLECT_THREADS);                 // 32 cost classes
+    uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + 32);              // 2 x COLLECT_THREADS
     for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
     for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
     __syncthreads();
@@ -205,9 +208,43 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const uint4 *gdesc = reinterpret_cast<const uint4 *>(F.desc);
     const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
     constexpr int WAVES = COLLECT_THREADS / 64;
-    const int lane = tid & 63;
-    for (int rowi = part * WAVES + (tid >> 6); rowi < waves_per_inst; rowi += wgs_per_inst * WAVES) {
-        const int qi = rowi * 64 + lane;
+    constexpr int SUPER = 2 * COLLECT_THREADS;      // queries sorted together: two rows of 64 per wave
+    const int lane = tid & 63, wave = tid >> 6;
+    // A wave costs what its widest window costs and window areas differ by more than 10x between pyramid levels, so
+    // the queries of a super-chunk are counting-sorted by the number of grid cells their window covers and each
+    // wave takes one heavy and one light group of 64 (results are still written at the query's own position).
+    const int n_super = (waves_per_inst * 64 + SUPER - 1) / SUPER;
+    for (int sc = part; sc < n_super; sc += wgs_per_inst) {
+        if (tid < 32) l_bucket[tid] = 0;
+        __syncthreads();
+        int cls[2], rank[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const Query t = load_params<MODE>(P, F, S, sc * SUPER + h * COLLECT_THREADS + tid);
+            int c = 0;
+            if (t.valid) {
+                const float xr = __fsub_rn(t.x, min_x), yr = __fsub_rn(t.y, min_y);
+                const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, t.r), inv_w)));
+                const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, t.r), inv_w)));
+                const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, t.r), inv_h)));
+                const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, t.r), inv_h)));
+                if (x1 >= x0 && y1 >= y0) c = min(31, 1 + ((x1 - x0 + 1) * (y1 - y0 + 1) >> 3));
+            }
+            cls[h] = c;
+            rank[h] = atomicAdd(&l_bucket[c], 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            int start = 0;
+            for (int bk = 31; bk > cls[h]; bk--) start += l_bucket[bk];
+            l_perm[start + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
+        }
+        __syncthreads();
+      for (int h = 0; h < 2; h++) {
+        const int group = h == 0 ? wave : 2 * WAVES - 1 - wave;
+        const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
+        const int rowi = qi >> 6;
         Query q = load_params<MODE>(P, F, S, qi);
         if (q.valid) load_desc<MODE>(S, qi, q);
         int ncand = 0;
@@ -250,26 +287,42 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
         wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
         const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
-        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + lane;
+        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + (qi & 63);
+        // claimable candidates (distance <= the acceptance threshold): up to three slot ids, their count in bits 48-49,
+        // bit 50 = "treat as live" (more than three, or more candidates than a row holds)
+        uint64_t pw = 0;
+        int npost = 0;
         for (int i = 0; i < wave_ncand; i++) {
-            uint32_t v = 0;
             if (i < ncand) {
-                v = l_cc[i * COLLECT_THREADS + tid];
+                uint32_t v = l_cc[i * COLLECT_THREADS + tid];
                 const int k = (int)(v & 0xFFFFu);
                 const uint4 dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
                 const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
-                v |= hamming256(qd, cd) << 20;
+                const uint32_t dist = hamming256(qd, cd);
+                v |= dist << 20;
+                row[i * 64] = v;
+                if ((int)dist <= P.dist_th) {
+                    if (npost < 3) pw |= (uint64_t)(uint32_t)k << (16 * npost);
+                    npost++;
+                }
             }
-            row[i * 64] = v;
         }
-        ncand_out[(size_t)inst * waves_per_inst * 64 + qi] = (uint8_t)min(ncand, 255);
+        pw |= (uint64_t)min(npost, 3) << 48;
+        if (npost > 3 || ncand > WIN_CACHE) pw |= 1ull << 50;
+        if (qi < waves_per_inst * 64) {
+            ncand_out[(size_t)inst * waves_per_inst * 64 + qi] = (uint8_t)min(ncand, 255);
+            postable_out[(size_t)inst * waves_per_inst * 64 + qi] = pw;
+        }
+      }
+        __syncthreads();     // l_perm and l_bucket are rewritten by the next super-chunk
     }
 }
 
 // ---- the claim loop.  PRE = false: collects inline (one kernel does everything; frame optionally staged in LDS).
 // PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
 template <int MODE, bool LDS_FRAME, bool PRE>
-__global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *cand, const uint8_t *ncand_in) {
+__global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *cand, const uint8_t *ncand_in,
+                              const uint64_t *postable_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameDev &F = P.frames[P.frame_ids[inst]];
@@ -328,27 +381,30 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     const uint8_t *nc_in = PRE ? ncand_in + (size_t)inst * waves_per_inst * 64 : nullptr;
     const uint32_t *rows = PRE ? cand + (size_t)inst * waves_per_inst * (WIN_CACHE * 64) : nullptr;
 
-    // one query per lane (claim priority = the query's index); the NEXT chunk's query is loaded while the current
-    // chunk is matched
-    auto load_query = [&](int qi, int &nc) {
+    auto load_nc = [&](int qi) { return (PRE && qi < Q) ? (int)nc_in[qi] : 0; };
+    auto load_query = [&](int qi, int nc) {
         Query q = load_params<MODE>(P, F, S, qi);
-        nc = 0;
         if (PRE) {
-            if (qi < Q) nc = nc_in[qi];
             if (nc > WIN_CACHE) load_desc<MODE>(S, qi, q);     // only the re-walking fallback compares descriptors here
         } else if (q.valid) {
             load_desc<MODE>(S, qi, q);
         }
         return q;
     };
+    auto wave_max = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto is_blocked = [&](uint32_t st, int dist) {
+        if (MODE == MODE_PROJ || MODE == MODE_LAST) return (st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS);   // :113-115 / :1879-1881
+        if (MODE == MODE_INIT) return (int)st <= dist;                                                     // :608
+        return (st & ORBM_MP_PRESENT) != 0;                                                                // :2048 / :512
+    };
 
-    int nc_next = 0;
-    Query nextq = load_query(tid, nc_next);
-    for (int base_q = 0; base_q < Q; base_q += nthr) {
-        const int qi = base_q + tid;
-        const Query cur = nextq;
-        const int nc_cur = nc_next;
-        nextq = load_query(qi + nthr, nc_next);
+    // One chunk of up to blockDim queries, one per lane, in ascending query index over tid (claim priority = tid).
+    // Called by every thread of the workgroup (barriers inside).
+    auto process_chunk = [&](const int qi, const Query &cur, const int nc_pre, uint32_t (&cc)[WIN_CACHE]) {
         bool unresolved = cur.valid;
         const uint32_t qd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
         const float x = cur.x, y = cur.y, r = cur.r, qangle = cur.angle;
@@ -360,11 +416,8 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         // remembered as k | oct << 16 | dist << 20 and the rounds below never walk again.  More than WIN_CACHE
         // candidates (wide windows): the rounds fall back to walking.
         int ncand = 0;
-        uint32_t cc[WIN_CACHE];
-#pragma unroll
-        for (int i = 0; i < WIN_CACHE; i++) cc[i] = 0;
         if (PRE) {
-            ncand = nc_cur;
+            ncand = nc_pre;
         } else if (unresolved) {
             auto collect = [&](int k, int oct, float ur) {
                 if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
@@ -382,15 +435,27 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         }
         if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
         const bool cached = ncand <= WIN_CACHE;
-        int wave_ncand = min(ncand, WIN_CACHE);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
-        wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
-        if (PRE) {
-            const uint32_t *row = rows + (size_t)(qi >> 6) * (WIN_CACHE * 64) + (qi & 63);
-#pragma unroll
-            for (int i = 0; i < WIN_CACHE; i++) if (i < wave_ncand) cc[i] = row[i * 64];
+        const int wave_ncand = wave_max(min(ncand, WIN_CACHE));
+
+        // A query none of whose claimable candidates (distance <= threshold) is still free can never be accepted, and
+        // blocked slots stay blocked, so it is settled without taking part in the rounds; a chunk with no live query
+        // costs one barrier.
+        if (cached && unresolved) {
+            bool live = false;
+            for (int i = 0; i < wave_ncand; i++) {
+                const uint32_t v = cc[i];
+                if (i < ncand && (int)(v >> 20) <= thr) {
+                    const uint32_t st = state[v & 0xFFFFu];
+                    bool blocked;
+                    if (MODE == MODE_PROJ || MODE == MODE_LAST) blocked = (st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS);
+                    else if (MODE == MODE_INIT) blocked = (int)st <= (int)(v >> 20);
+                    else blocked = (st & ORBM_MP_PRESENT) != 0;
+                    if (!blocked) live = true;
+                }
+            }
+            unresolved = live;
         }
+        if (!__syncthreads_or(unresolved ? 1 : 0)) return;
 
         int round = 0;
         while (true) {
@@ -493,6 +558,80 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             for (int i = tid; i < n; i += nthr) post[i] = NOPOST;
         }
         __syncthreads();
+
+    };
+
+    if (!PRE) {
+        // single-kernel form: queries in index order, the NEXT chunk's query is loaded while the current one is matched
+        Query nextq = load_query(tid, 0);
+        for (int base_q = 0; base_q < Q; base_q += nthr) {
+            const int qi = base_q + tid;
+            const Query cur = nextq;
+            nextq = load_query(qi + nthr, 0);
+            uint32_t cc[WIN_CACHE];
+#pragma unroll
+            for (int i = 0; i < WIN_CACHE; i++) cc[i] = 0;
+            process_chunk(qi, cur, 0, cc);
+        }
+    } else {
+        // split form.  collect_kernel left one word per query naming its claimable candidates (distance <= threshold).
+        // A query none of whose claimable candidates is still free can never be accepted, and blocked slots stay
+        // blocked, so the queries are first scanned SCAN_U x blockDim at a time against the current slot state (a few
+        // instructions each, loads independent) and only the live ones, compacted in index order, go through the
+        // rounds.  Typical inputs leave a few percent of the queries live.
+        uint16_t *qlist = reinterpret_cast<uint16_t *>(hist + 64);          // SCAN_U x blockDim
+        int *cnts = hist + 64 + SCAN_U * nthr / 2;                          // SCAN_U x waves (+1)
+        int *pre = cnts + SCAN_U * 16 + 1;
+        const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
+        const uint64_t *pw = postable_in + (size_t)inst * waves_per_inst * 64;
+        for (int sb = 0; sb < Q; sb += SCAN_U * nthr) {
+            uint64_t w[SCAN_U];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const int qi = sb + u * nthr + tid;
+                w[u] = qi < Q ? pw[qi] : 0ull;
+            }
+            uint32_t lm = 0, ranks = 0, rankhi = 0;
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                bool live = (w[u] >> 50) & 1ull;
+                const int c = (int)((w[u] >> 48) & 3ull);
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (j < c && !is_blocked(state[(uint32_t)(w[u] >> (16 * j)) & 0xFFFFu], 0)) live = true;
+                const uint64_t m = __ballot(live);
+                if (lane == 0) cnts[u * NW + wave] = __popcll(m);
+                const uint32_t rk = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (u < 4) ranks |= rk << (8 * u); else rankhi |= rk << (8 * (u - 4));
+                if (live) lm |= 1u << u;
+            }
+            __syncthreads();
+            if (tid < SCAN_U * NW) {
+                int sum = 0;
+                for (int e2 = 0; e2 < tid; e2++) sum += cnts[e2];
+                pre[tid] = sum;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++)
+                if ((lm >> u) & 1u) {
+                    const uint32_t rk = u < 4 ? (ranks >> (8 * u)) & 0xFFu : (rankhi >> (8 * (u - 4))) & 0xFFu;
+                    qlist[pre[u * NW + wave] + rk] = (uint16_t)(u * nthr + tid);
+                }
+            const int nlive = pre[SCAN_U * NW - 1] + cnts[SCAN_U * NW - 1];
+            __syncthreads();
+            for (int c0 = 0; c0 < nlive; c0 += nthr) {
+                const int li = c0 + tid;
+                const int qi = li < nlive ? sb + (int)qlist[li] : Q;
+                const int nc = load_nc(qi);
+                const Query cur = load_query(qi, nc);
+                uint32_t cc[WIN_CACHE];
+                const uint32_t *row = rows + (size_t)(qi >> 6) * (WIN_CACHE * 64) + (qi & 63);
+#pragma unroll
+                for (int i = 0; i < WIN_CACHE; i++) cc[i] = i < min(nc, WIN_CACHE) ? row[i * 64] : 0u;
+                process_chunk(qi, cur, nc, cc);
+            }
+        }
     }
 
     if (my_matches) atomicAdd(nmatch, my_matches);
@@ -593,14 +732,15 @@ constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B de
 
 template <int MODE, bool LDS_FRAME, bool PRE>
 int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
-                  const uint32_t *cand, const uint8_t *ncand) {
-    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64) * 4;
+                  const uint32_t *cand, const uint8_t *ncand, const uint64_t *postable) {
+    const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
+                        (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
     if (lds > 48 * 1024) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME, PRE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
-                       waves_per_inst, cand, ncand);
+                       waves_per_inst, cand, ncand, postable);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
@@ -613,33 +753,34 @@ template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
     // MODE_INIT: one window size, hundreds of candidates; frames too large for collect_kernel's LDS staging
     const bool single = MODE == MODE_INIT || g_win_variant != 0 ||
-                        (3076 + 4 * (size_t)max_n + (size_t)WIN_CACHE * COLLECT_THREADS) * 4 > 160 * 1024;
+                        (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + 32) * 4 > 160 * 1024;
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
-            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr);
-        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr);
+            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr);
+        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, nullptr);
     }
     if (MODE != MODE_INIT) {
         const int waves_per_inst = (max_q + 63) / 64;
-        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr);
+        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr, nullptr);
         const size_t rows = (size_t)n_inst * waves_per_inst;
         const size_t cand_bytes = rows * WIN_CACHE * 64 * 4;
-        int rc = orbm_ws2_reserve(ctx, cand_bytes + rows * 64 + 256);
+        int rc = orbm_ws2_reserve(ctx, cand_bytes + rows * 64 * 9 + 256);
         if (rc) return rc;
         uint32_t *cand = (uint32_t *)ctx->ws2;
-        uint8_t *ncand = (uint8_t *)ctx->ws2 + cand_bytes;
+        uint64_t *postable = (uint64_t *)((char *)ctx->ws2 + cand_bytes);
+        uint8_t *ncand = (uint8_t *)ctx->ws2 + cand_bytes + rows * 64 * 8;
         // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
         constexpr int WAVES = COLLECT_THREADS / 64;
-        int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
-        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)WIN_CACHE * COLLECT_THREADS) * 4;
+        int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
+        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + 32) * 4;
         if (lds > 48 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, cand, ncand);
+                           waves_per_inst, wgs_per_inst, cand, ncand, postable);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
-        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand);
+        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable);
     }
     return ORBM_OK;
 }

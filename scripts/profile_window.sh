@@ -12,10 +12,11 @@ python3 - <<PY
 import csv, glob, collections
 for sub in ("sq1", "sq2"):
     f = glob.glob("$OUT/%s/*/*_counter_collection.csv" % sub)[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "window_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        print("%-24s %14.0f  (x%d)" % (k, sum(v) / len(v), len(v)))
+    for kern in ("collect_kernel", "window_kernel"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            print("%-16s %-24s %14.0f  (x%d)" % (kern, k, sum(v) / len(v), len(v)))
 PY
