@@ -189,7 +189,8 @@ constexpr int COLLECT_THREADS = 512;
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  uint32_t *cand, uint8_t *ncand_out, uint64_t *postable_out) {
+                                                                  uint32_t *cand, uint32_t *cand_hi, uint8_t *ncand_out,
+                                                                  uint64_t *postable_out, int cap) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
     const int tid = threadIdx.x;
@@ -247,30 +248,51 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         const int rowi = qi >> 6;
         Query q = load_params<MODE>(P, F, S, qi);
         if (q.valid) load_desc<MODE>(S, qi, q);
-        int ncand = 0;
-        if (q.valid) {
-            // Frame.cc:434-498 / KeyFrame.cc:766-812, as walk_window()
-            const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
-            const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
-            const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
-            const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
-            const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
-            const bool empty = x0 >= ORBM_GRID_COLS || x1 < 0 || y0 >= ORBM_GRID_ROWS || y1 < 0;
-            // level gates: Frame's GetFeaturesInArea filters when minLevel > 0 or maxLevel >= 0 (a negative maxLevel
-            // leaves the top open); KeyFrame's does not filter, SearchByProjection(KF, Scw, ...) does it itself (:515-518)
-            int lo = -1, hi = 255;
-            if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
-            else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+        // Frame.cc:434-498 / KeyFrame.cc:766-812, as walk_window()
+        const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
+        const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
+        const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
+        const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
+        const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
+        // level gates: Frame's GetFeaturesInArea filters when minLevel > 0 or maxLevel >= 0 (a negative maxLevel
+        // leaves the top open); KeyFrame's does not filter, SearchByProjection(KF, Scw, ...) does it itself (:515-518)
+        int lo = -1, hi = 255;
+        if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
+        else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+        const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
+        // candidates 0..WIN_CACHE-1 of a query live in `cand`, the rest (up to cap) in `cand_hi`
+        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + (qi & 63);
+        uint32_t *row_hi = cand_hi + ((size_t)inst * waves_per_inst + rowi) * ((size_t)(cap - WIN_CACHE) * 64) + (qi & 63);
+        // claimable candidates (distance <= the acceptance threshold): up to three slot ids, their count in bits 48-49,
+        // bit 50 = "treat as live" (more than three, or more candidates than a row holds)
+        uint64_t pw = 0;
+        int npost = 0;
+        int ncand = 0;      // candidates that passed the static gates
+        auto finish = [&](uint32_t v) {                         // v = k | oct << 16 -> adds the distance, notes claimables
+            const int k = (int)(v & 0xFFFFu);
+            const uint4 dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
+            const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
+            const uint32_t dist = hamming256(qd, cd);
+            if ((int)dist <= P.dist_th) {
+                if (npost < 3) pw |= (uint64_t)(uint32_t)k << (16 * npost);
+                npost++;
+            }
+            return v | (dist << 20);
+        };
+        // first phase: a single flat loop over the window's records (a column change is just another iteration);
+        // survivors are parked (LDS for the first WIN_CACHE, the row itself beyond) until the second phase
+        if (q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0) {
             int ix = x0 - 1;
             uint32_t j = 0, e = 0;
-            if (!empty)
-                for (;;) {
-                    if (j >= e) {                                  // next column: one contiguous run of records
-                        if (++ix > x1) break;
+            bool more = true;
+            while (more) {
+                if (j >= e) {                                  // next column: one contiguous run of records
+                    if (++ix > x1) more = false;
+                    else {
                         j = l_cell[ix * ORBM_GRID_ROWS + y0];
                         e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
-                        continue;
                     }
+                } else {
                     const float4 rc = l_rec[j++];
                     const uint32_t w = __float_as_uint(rc.w);
                     const int oct = (int)(w >> 16);
@@ -278,37 +300,28 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                     if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
                     if (pass) {
                         if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = w;
+                        else if (ncand < cap) row_hi[(ncand - WIN_CACHE) * 64] = w;
                         ncand++;
                     }
                 }
-        }
-        int wave_ncand = min(ncand, WIN_CACHE);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wave_ncand = max(wave_ncand, __shfl_xor(wave_ncand, off, 64));
-        wave_ncand = __builtin_amdgcn_readfirstlane(wave_ncand);
-        const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
-        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + (qi & 63);
-        // claimable candidates (distance <= the acceptance threshold): up to three slot ids, their count in bits 48-49,
-        // bit 50 = "treat as live" (more than three, or more candidates than a row holds)
-        uint64_t pw = 0;
-        int npost = 0;
-        for (int i = 0; i < wave_ncand; i++) {
-            if (i < ncand) {
-                uint32_t v = l_cc[i * COLLECT_THREADS + tid];
-                const int k = (int)(v & 0xFFFFu);
-                const uint4 dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
-                const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
-                const uint32_t dist = hamming256(qd, cd);
-                v |= dist << 20;
-                row[i * 64] = v;
-                if ((int)dist <= P.dist_th) {
-                    if (npost < 3) pw |= (uint64_t)(uint32_t)k << (16 * npost);
-                    npost++;
-                }
+                // keeps this ONE loop: without a convergent operation here the compiler splits it into nested
+                // "advance until a survivor" loops, and lanes then wait for each other at every survivor
+                __builtin_amdgcn_wave_barrier();
             }
         }
+        // second phase: Hamming distances, wave-uniform trip counts
+        {
+            int wn = min(ncand, cap);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wn = max(wn, __shfl_xor(wn, off, 64));
+            wn = __builtin_amdgcn_readfirstlane(wn);
+            for (int i = 0; i < min(wn, WIN_CACHE); i++)
+                if (i < ncand) row[i * 64] = finish(l_cc[i * COLLECT_THREADS + tid]);
+            for (int i = WIN_CACHE; i < wn; i++)
+                if (i < ncand) row_hi[(i - WIN_CACHE) * 64] = finish(row_hi[(i - WIN_CACHE) * 64]);
+        }
         pw |= (uint64_t)min(npost, 3) << 48;
-        if (npost > 3 || ncand > WIN_CACHE) pw |= 1ull << 50;
+        if (npost > 3 || ncand > cap) pw |= 1ull << 50;
         if (qi < waves_per_inst * 64) {
             ncand_out[(size_t)inst * waves_per_inst * 64 + qi] = (uint8_t)min(ncand, 255);
             postable_out[(size_t)inst * waves_per_inst * 64 + qi] = pw;
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 // PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
 template <int MODE, bool LDS_FRAME, bool PRE>
 __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *cand, const uint8_t *ncand_in,
-                              const uint64_t *postable_in) {
+                              const uint64_t *postable_in, int cap, const uint32_t *cand_hi) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameDev &F = P.frames[P.frame_ids[inst]];
@@ -380,12 +393,13 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     int my_matches = 0;
     const uint8_t *nc_in = PRE ? ncand_in + (size_t)inst * waves_per_inst * 64 : nullptr;
     const uint32_t *rows = PRE ? cand + (size_t)inst * waves_per_inst * (WIN_CACHE * 64) : nullptr;
+    const uint32_t *rows_hi = PRE ? cand_hi + (size_t)inst * waves_per_inst * ((size_t)(cap - WIN_CACHE) * 64) : nullptr;
 
     auto load_nc = [&](int qi) { return (PRE && qi < Q) ? (int)nc_in[qi] : 0; };
     auto load_query = [&](int qi, int nc) {
         Query q = load_params<MODE>(P, F, S, qi);
         if (PRE) {
-            if (nc > WIN_CACHE) load_desc<MODE>(S, qi, q);     // only the re-walking fallback compares descriptors here
+            if (nc > cap) load_desc<MODE>(S, qi, q);           // only the re-walking fallback compares descriptors here
         } else if (q.valid) {
             load_desc<MODE>(S, qi, q);
         }
@@ -434,8 +448,15 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             else walk_window<false>(acc, x, y, r, minL, maxL, collect);
         }
         if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
-        const bool cached = ncand <= WIN_CACHE;
-        const int wave_ncand = wave_max(min(ncand, WIN_CACHE));
+        // candidate i of this lane's query: the first WIN_CACHE in registers, the rest (split form, rows of `cap`
+        // entries) re-read from the row; i is wave-uniform
+        const bool cached = ncand <= cap;
+        const int wave_ncand = wave_max(min(ncand, cap));
+        const uint32_t *myrow_hi = PRE ? rows_hi + (size_t)(qi >> 6) * ((size_t)(cap - WIN_CACHE) * 64) + (qi & 63) : nullptr;
+        auto cand_at = [&](int i) -> uint32_t {
+            if (i < WIN_CACHE) return cc[i];
+            return (PRE && i < ncand) ? myrow_hi[(i - WIN_CACHE) * 64] : 0u;
+        };
 
         // A query none of whose claimable candidates (distance <= threshold) is still free can never be accepted, and
         // blocked slots stay blocked, so it is settled without taking part in the rounds; a chunk with no live query
@@ -443,7 +464,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         if (cached && unresolved) {
             bool live = false;
             for (int i = 0; i < wave_ncand; i++) {
-                const uint32_t v = cc[i];
+                const uint32_t v = cand_at(i);
                 if (i < ncand && (int)(v >> 20) <= thr) {
                     const uint32_t st = state[v & 0xFFFFu];
                     bool blocked;
@@ -486,7 +507,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 if (cached) {
                     // wave-uniform trip count: the register array is indexed by a scalar (v_movrels), no unrolling
                     for (int i = 0; i < wave_ncand; i++) {
-                        const uint32_t v = cc[i];
+                        const uint32_t v = cand_at(i);
                         if (i < ncand) consider((int)(v & 0xFFFFu), (int)((v >> 16) & 15u), (int)(v >> 20));
                     }
                 } else {
@@ -506,7 +527,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 bool is_final = true;
                 if (cached) {
                     for (int i = 0; i < wave_ncand; i++) {
-                        const uint32_t v = cc[i];
+                        const uint32_t v = cand_at(i);
                         if (i < ncand && post[v & 0xFFFFu] < (uint32_t)tid) is_final = false;
                     }
                 } else {
@@ -732,7 +753,8 @@ constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B de
 
 template <int MODE, bool LDS_FRAME, bool PRE>
 int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
-                  const uint32_t *cand, const uint8_t *ncand, const uint64_t *postable) {
+                  const uint32_t *cand, const uint8_t *ncand, const uint64_t *postable, int cap,
+                  const uint32_t *cand_hi = nullptr) {
     const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
                         (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
     if (lds > 48 * 1024) {
@@ -740,7 +762,7 @@ int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
-                       waves_per_inst, cand, ncand, postable);
+                       waves_per_inst, cand, ncand, postable, cap, cand_hi);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
@@ -756,17 +778,22 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
                         (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + 32) * 4 > 160 * 1024;
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
-            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr);
-        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, nullptr);
+            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr, WIN_CACHE);
+        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, nullptr, WIN_CACHE);
     }
     if (MODE != MODE_INIT) {
         const int waves_per_inst = (max_q + 63) / 64;
-        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr, nullptr);
+        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr, nullptr, WIN_CACHE);
         const size_t rows = (size_t)n_inst * waves_per_inst;
-        const size_t cand_bytes = rows * WIN_CACHE * 64 * 4;
+        // candidates kept per query: 64 unless the batch is so large that the rows would not fit 8 GB (queries with
+        // more candidates than that are still exact: the claims kernel re-walks their window)
+        int cap = 64;
+        while (cap > WIN_CACHE && rows * cap * 256 > ((size_t)8 << 30)) cap >>= 1;
+        const size_t cand_bytes = rows * cap * 64 * 4;
         int rc = orbm_ws2_reserve(ctx, cand_bytes + rows * 64 * 9 + 256);
         if (rc) return rc;
-        uint32_t *cand = (uint32_t *)ctx->ws2;
+        uint32_t *cand = (uint32_t *)ctx->ws2;                                   // rows x WIN_CACHE x 64
+        uint32_t *cand_hi = cand + rows * WIN_CACHE * 64;                        // rows x (cap - WIN_CACHE) x 64
         uint64_t *postable = (uint64_t *)((char *)ctx->ws2 + cand_bytes);
         uint8_t *ncand = (uint8_t *)ctx->ws2 + cand_bytes + rows * 64 * 8;
         // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
@@ -777,10 +804,10 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, cand, ncand, postable);
+                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
-        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable);
+        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable, cap, cand_hi);
     }
     return ORBM_OK;
 }

@@ -4,7 +4,7 @@ TH=${1:-3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/trace_win_$TH
 rm -rf $OUT && mkdir -p $OUT
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 scripts/proj_prof.py $TH > $OUT/kt.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 scripts/proj_prof.py $TH ${2:-512} > $OUT/kt.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/kt/*/*_kernel_stats.csv")[0]

@@ -215,7 +215,8 @@ def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
     L = _lib.load()
     try:
         L.orbm__window_variant(variant)
-        for seed, n, nq, th, stereo in ((901, 3000, 8000, 3.0, False), (902, 800, 5000, 5.0, True), (904, 2000, 3000, 1.0, False)):
+        for seed, n, nq, th, stereo in ((901, 3000, 8000, 3.0, False), (902, 800, 5000, 5.0, True), (904, 2000, 3000, 1.0, False),
+                                         (905, 2000, 3000, 8.0, True)):   # th 8: more candidates than a row holds
             f, q = synth.proj_instance(seed=seed, n=n, n_queries=nq, claimed_frac=0.1, obs_frac=0.7, stereo=stereo)
             fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
             counts, owner = ctx.search_proj_points(fid, qid, th, 0.8, stride=n)
@@ -223,12 +224,13 @@ def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
             assert counts[0] == wc and np.array_equal(owner[0], wo), (seed, variant)
             ctx.free_frames(fid); ctx.free_queries(qid)
         for mode in (0, 1, 2):
-            f, q = synth.window_instance(960 + mode, mode, n=1500, n_queries=2500, stereo=(mode == 0), th=7.0)
-            fid = ctx.upload_frames([f]); qid = ctx.upload_win_queries([q])
-            counts, owner = ctx.search_window(mode, fid, qid, 100 if mode < 2 else 50, mode < 2, stride=1500)
-            wc, wo, _ = orc.search_window(mode, f, q, 100 if mode < 2 else 50, mode < 2)
-            assert counts[0] == wc and np.array_equal(owner[0], wo), (mode, variant)
-            ctx.free_frames(fid); ctx.free_queries(qid)
+            for wth in (7.0, 15.0):
+                f, q = synth.window_instance(960 + mode, mode, n=1500, n_queries=2500, stereo=(mode == 0), th=wth)
+                fid = ctx.upload_frames([f]); qid = ctx.upload_win_queries([q])
+                counts, owner = ctx.search_window(mode, fid, qid, 100 if mode < 2 else 50, mode < 2, stride=1500)
+                wc, wo, _ = orc.search_window(mode, f, q, 100 if mode < 2 else 50, mode < 2)
+                assert counts[0] == wc and np.array_equal(owner[0], wo), (mode, wth, variant)
+                ctx.free_frames(fid); ctx.free_queries(qid)
     finally:
         L.orbm__window_variant(0)
 
