@@ -186,6 +186,7 @@ __device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
 // stored as k | oct << 16 | dist << 20 in reference visit order, in rows of 64 lanes (row i of a wave = candidate i
 // of its 64 queries; only rows some lane needs are written).
 constexpr int COLLECT_THREADS = 512;
+constexpr int COST_CLASSES = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     uint32_t *l_cell = lds;                                                      // 3076
     float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);                      // 4n
     uint32_t *l_cc = lds + 3076 + 4 * (size_t)n;                                 // WIN_CACHE x COLLECT_THREADS
-    int *l_bucket = (int *)(l_cc + WIN_CACHE * COLLECT_THREADS);                 // 32 cost classes
-    uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + 32);              // 2 x COLLECT_THREADS
+    int *l_bucket = (int *)(l_cc + WIN_CACHE * COLLECT_THREADS);                 // cost classes
+    uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + COST_CLASSES);    // 2 x COLLECT_THREADS
     for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
     for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
     __syncthreads();
@@ -212,11 +213,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     constexpr int SUPER = 2 * COLLECT_THREADS;      // queries sorted together: two rows of 64 per wave
     const int lane = tid & 63, wave = tid >> 6;
     // A wave costs what its widest window costs and window areas differ by more than 10x between pyramid levels, so
-    // the queries of a super-chunk are counting-sorted by the number of grid cells their window covers and each
+    // the queries of a super-chunk are counting-sorted by the length of their walk (columns + records) and each
     // wave takes one heavy and one light group of 64 (results are still written at the query's own position).
     const int n_super = (waves_per_inst * 64 + SUPER - 1) / SUPER;
     for (int sc = part; sc < n_super; sc += wgs_per_inst) {
-        if (tid < 32) l_bucket[tid] = 0;
+        if (tid < COST_CLASSES) l_bucket[tid] = 0;
         __syncthreads();
         int cls[2], rank[2];
 #pragma unroll
@@ -229,7 +230,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, t.r), inv_w)));
                 const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, t.r), inv_h)));
                 const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, t.r), inv_h)));
-                if (x1 >= x0 && y1 >= y0) c = min(31, 1 + ((x1 - x0 + 1) * (y1 - y0 + 1) >> 3));
+                if (x1 >= x0 && y1 >= y0) {
+                    int cnt = x1 - x0 + 1;                     // loop iterations of the walk: columns + records
+                    for (int ix = x0; ix <= x1; ix++)
+                        cnt += (int)(l_cell[ix * ORBM_GRID_ROWS + y1 + 1] - l_cell[ix * ORBM_GRID_ROWS + y0]);
+                    c = cnt < 62 ? 1 + (cnt >> 1) : min(COST_CLASSES - 1, 32 + ((cnt - 62) >> 4));
+                }
             }
             cls[h] = c;
             rank[h] = atomicAdd(&l_bucket[c], 1);
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             int start = 0;
-            for (int bk = 31; bk > cls[h]; bk--) start += l_bucket[bk];
+            for (int bk = COST_CLASSES - 1; bk > cls[h]; bk--) start += l_bucket[bk];
             l_perm[start + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
         }
         __syncthreads();
@@ -775,7 +781,7 @@ template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
     // MODE_INIT: one window size, hundreds of candidates; frames too large for collect_kernel's LDS staging
     const bool single = MODE == MODE_INIT || g_win_variant != 0 ||
-                        (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + 32) * 4 > 160 * 1024;
+                        (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + COST_CLASSES) * 4 > 160 * 1024;
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
             return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr, WIN_CACHE);
@@ -799,7 +805,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
         constexpr int WAVES = COLLECT_THREADS / 64;
         int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
-        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + 32) * 4;
+        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + COST_CLASSES) * 4;
         if (lds > 48 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
