@@ -19,6 +19,7 @@ int orbm_fail(orbm_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t PIN_MAX_BYTES = (size_t)256 << 20;
 
 int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return ORBM_OK;
@@ -27,7 +28,56 @@ int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes) {
     size_t cap = align_up(bytes + bytes / 4, 1 << 20);
     HIPCHK(ctx, hipMalloc(&ctx->ws, cap));
     ctx->ws_bytes = cap;
+    // pinned mirror (skipped for very large staging areas: those calls are bandwidth-, not latency-bound)
+    if (ctx->pin) { (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+    if (cap <= PIN_MAX_BYTES && hipHostMalloc(&ctx->pin, cap, hipHostMallocDefault) == hipSuccess) ctx->pin_bytes = cap;
+    else { ctx->pin = nullptr; (void)hipGetLastError(); }
     return ORBM_OK;
+}
+
+void *orbm_pin_up(orbm_ctx *ctx, size_t bytes) {
+    if (bytes > PIN_MAX_BYTES) return nullptr;
+    if (bytes <= ctx->pin_up_bytes) return ctx->pin_up;
+    if (ctx->pin_up) { (void)hipHostFree(ctx->pin_up); ctx->pin_up = nullptr; ctx->pin_up_bytes = 0; }
+    size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+    if (hipHostMalloc(&ctx->pin_up, cap, hipHostMallocDefault) != hipSuccess) { ctx->pin_up = nullptr; (void)hipGetLastError(); return nullptr; }
+    ctx->pin_up_bytes = cap;
+    return ctx->pin_up;
+}
+
+constexpr size_t ARENA_POOL_MAX_ENTRIES = 16;
+constexpr size_t ARENA_POOL_MAX_BYTES = (size_t)256 << 20;
+
+int orbm_arena_alloc(orbm_ctx *ctx, size_t bytes, Arena *out) {
+    if (bytes == 0) bytes = 256;
+    int best = -1;
+    for (size_t i = 0; i < ctx->arena_pool.size(); i++) {
+        const Arena &c = ctx->arena_pool[i];
+        if (c.cap >= bytes && c.cap <= 4 * bytes + (1 << 20) && (best < 0 || c.cap < ctx->arena_pool[best].cap)) best = (int)i;
+    }
+    if (best >= 0) {
+        *out = ctx->arena_pool[best];
+        ctx->arena_pool_bytes -= out->cap;
+        ctx->arena_pool.erase(ctx->arena_pool.begin() + best);
+    } else {
+        *out = Arena();
+        out->cap = align_up(bytes, 4096);
+        HIPCHK(ctx, hipMalloc(&out->base, out->cap));
+    }
+    out->bytes = bytes;
+    out->live = 0;
+    return ORBM_OK;
+}
+
+void orbm_arena_release(orbm_ctx *ctx, Arena &a) {
+    if (!a.base) return;
+    if (ctx->arena_pool.size() < ARENA_POOL_MAX_ENTRIES && ctx->arena_pool_bytes + a.cap <= ARENA_POOL_MAX_BYTES) {
+        ctx->arena_pool.push_back(a);
+        ctx->arena_pool_bytes += a.cap;
+    } else {
+        (void)hipFree(a.base);
+    }
+    a = Arena();
 }
 
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes) {
@@ -48,15 +98,31 @@ void *IoStage::carve(size_t bytes) {
 
 int IoStage::in(const void *p, size_t bytes, const void **devp) {
     if (dev || p == nullptr) { *devp = p; return ORBM_OK; }
+    const size_t off = used;
     void *d = carve(bytes);
     if (used > ctx->ws_bytes) return orbm_fail(ctx, ORBM_ENOMEM, "I/O staging workspace overflow");
-    HIPCHK(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->pin && !in_sent) {           // staged: goes out with send_inputs() as one copy
+        memcpy((char *)ctx->pin + off, p, bytes);
+        in_end = used;
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     *devp = d;
     return ORBM_OK;
 }
 
+int IoStage::send_inputs() {
+    if (dev || in_sent) return ORBM_OK;
+    in_sent = true;
+    if (in_end) HIPCHK(ctx, hipMemcpyAsync(ctx->ws, ctx->pin, in_end, hipMemcpyHostToDevice, ctx->stream));
+    return ORBM_OK;
+}
+
+// every entry point registers its inputs first, then its outputs, then launches: the first out() sends the inputs
 int IoStage::out(void *p, size_t bytes, void **devp) {
+    if (!dev) { int rc = send_inputs(); if (rc) return rc; }
     if (dev || p == nullptr) { *devp = p; return ORBM_OK; }
+    if (outs.empty()) out_begin = used;
     void *d = carve(bytes);
     if (used > ctx->ws_bytes) return orbm_fail(ctx, ORBM_ENOMEM, "I/O staging workspace overflow");
     outs.push_back({p, d, bytes});
@@ -66,6 +132,14 @@ int IoStage::out(void *p, size_t bytes, void **devp) {
 
 int IoStage::finish() {
     if (dev) return ORBM_OK;
+    { int rc = send_inputs(); if (rc) return rc; }
+    if (ctx->pin && !outs.empty()) {      // one D2H copy of the whole output region into the pinned mirror
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->pin + out_begin, (char *)ctx->ws + out_begin, used - out_begin,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto &o : outs) memcpy(o.host, (char *)ctx->pin + ((char *)o.devp - (char *)ctx->ws), o.bytes);
+        return ORBM_OK;
+    }
     for (auto &o : outs) HIPCHK(ctx, hipMemcpyAsync(o.host, o.devp, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ORBM_OK;
@@ -224,9 +298,12 @@ void orbm_destroy(orbm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &a : ctx->arenas) if (a.base) (void)hipFree(a.base);
+    for (auto &a : ctx->arena_pool) if (a.base) (void)hipFree(a.base);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_qsets) (void)hipFree(ctx->d_qsets);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin_up) (void)hipHostFree(ctx->pin_up);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -327,10 +404,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4);
     }
     Arena ar;
-    ar.bytes = pk.off;
-    HIPCHK(ctx, hipMalloc(&ar.base, ar.bytes));
-    hipError_t e = hipMemcpy(ar.base, pk.host.data(), ar.bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(ar.base); return orbm_fail(ctx, ORBM_EHIP, "frame upload copy failed: %s", hipGetErrorString(e)); }
+    { int rc = orbm_arena_alloc(ctx, pk.off, &ar); if (rc) return rc; }
     ar.live = n_frames;
     int arena_id = -1;
     for (size_t i = 0; i < ctx->arenas.size(); i++) if (!ctx->arenas[i].base) { arena_id = (int)i; break; }
@@ -370,11 +444,24 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
     int rc = grow_table(ctx, (void **)&ctx->d_frames, &ctx->d_frames_cap, ctx->h_frames.size(), sizeof(FrameDev));
     if (rc) return rc;
     if (ctx->d_frames_cap != old_cap) { lo = 0; hi = ctx->h_frames.size() - 1; }
-    HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, (hi - lo + 1) * sizeof(FrameDev), hipMemcpyHostToDevice));
-    // build the grid-cell CSR on the device
     rc = orbm_ws_reserve(ctx, (size_t)n_frames * 4);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ws, out_ids, (size_t)n_frames * 4, hipMemcpyHostToDevice, ctx->stream));
+    // data, table slice and id list go through one pinned block when it fits (three stream-ordered copies, one sync)
+    const size_t tab_bytes = (hi - lo + 1) * sizeof(FrameDev), id_bytes = (size_t)n_frames * 4;
+    const size_t o_tab = align_up(pk.off, 256), o_ids = o_tab + align_up(tab_bytes, 256);
+    if (char *pin = (char *)orbm_pin_up(ctx, o_ids + id_bytes)) {
+        memcpy(pin, pk.host.data(), pk.off);
+        memcpy(pin + o_tab, ctx->h_frames.data() + lo, tab_bytes);
+        memcpy(pin + o_ids, out_ids, id_bytes);
+        HIPCHK(ctx, hipMemcpyAsync(ar.base, pin, pk.off, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames + lo, pin + o_tab, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws, pin + o_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpy(ar.base, pk.host.data(), pk.off, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, tab_bytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws, out_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // build the grid-cell CSR on the device
     hipLaunchKernelGGL(build_grid_kernel, dim3(n_frames), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -383,7 +470,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
 
 static void arena_unref(orbm_ctx *ctx, int a) {
     if (a < 0) return;
-    if (--ctx->arenas[a].live == 0) { (void)hipFree(ctx->arenas[a].base); ctx->arenas[a] = Arena(); }
+    if (--ctx->arenas[a].live == 0) orbm_arena_release(ctx, ctx->arenas[a]);
 }
 
 int orbm_frames_free(orbm_ctx *ctx, int n_frames, const int32_t *ids) {
@@ -462,12 +549,7 @@ static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, 
         }
     }
     Arena ar;
-    ar.bytes = pk.off ? pk.off : 256;
-    HIPCHK(ctx, hipMalloc(&ar.base, ar.bytes));
-    if (pk.off) {
-        hipError_t e = hipMemcpy(ar.base, pk.host.data(), pk.off, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(ar.base); return orbm_fail(ctx, ORBM_EHIP, "query upload copy failed: %s", hipGetErrorString(e)); }
-    }
+    { int rc = orbm_arena_alloc(ctx, pk.off, &ar); if (rc) return rc; }
     ar.live = n_sets;
     int arena_id = -1;
     for (size_t i = 0; i < ctx->arenas.size(); i++) if (!ctx->arenas[i].base) { arena_id = (int)i; break; }
@@ -496,7 +578,18 @@ static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, 
     int rc = grow_table(ctx, (void **)&ctx->d_qsets, &ctx->d_qsets_cap, ctx->h_qsets.size(), sizeof(QSetDev));
     if (rc) return rc;
     if (ctx->d_qsets_cap != old_cap) { lo = 0; hi = ctx->h_qsets.size() - 1; }
-    HIPCHK(ctx, hipMemcpy(ctx->d_qsets + lo, ctx->h_qsets.data() + lo, (hi - lo + 1) * sizeof(QSetDev), hipMemcpyHostToDevice));
+    const size_t tab_bytes = (hi - lo + 1) * sizeof(QSetDev), o_tab = align_up(pk.off, 256);
+    if (char *pin = (char *)orbm_pin_up(ctx, o_tab + tab_bytes)) {
+        // stream-ordered pinned copies: the searches that follow on this context's stream see the data
+        if (pk.off) memcpy(pin, pk.host.data(), pk.off);
+        memcpy(pin + o_tab, ctx->h_qsets.data() + lo, tab_bytes);
+        if (pk.off) HIPCHK(ctx, hipMemcpyAsync(ar.base, pin, pk.off, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_qsets + lo, pin + o_tab, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the pinned block is reused by the next upload
+    } else {
+        if (pk.off) HIPCHK(ctx, hipMemcpy(ar.base, pk.host.data(), pk.off, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->d_qsets + lo, ctx->h_qsets.data() + lo, tab_bytes, hipMemcpyHostToDevice));
+    }
     return ORBM_OK;
 }
 

@@ -39,8 +39,9 @@ struct QSetDev {
 
 struct Arena {
     void *base = nullptr;
-    size_t bytes = 0;
-    int live = 0;  // objects still referencing it
+    size_t bytes = 0;   // bytes in use
+    size_t cap = 0;     // bytes allocated
+    int live = 0;       // objects still referencing it
 };
 
 struct orbm_ctx {
@@ -62,9 +63,19 @@ struct orbm_ctx {
     QSetDev *d_qsets = nullptr;
     size_t d_qsets_cap = 0;
     std::vector<Arena> arenas;
+    // released arenas kept for reuse: per-call uploads of the drop-in class (a frame, a query set) would otherwise
+    // pay a hipMalloc + hipFree each; bounded in count and bytes
+    std::vector<Arena> arena_pool;
+    size_t arena_pool_bytes = 0;
     // grow-only workspace for staged host I/O and kernel scratch
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // pinned host mirrors: `pin` shadows ws (host-mode index lists and outputs travel as ONE copy each way),
+    // `pin_up` stages uploads.  Pageable copies cost ~70 us each on this platform, pinned ones ~10.
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+    void *pin_up = nullptr;
+    size_t pin_up_bytes = 0;
     void *ws2 = nullptr;   // kernel scratch (separate from I/O staging)
     size_t ws2_bytes = 0;
 };
@@ -78,7 +89,10 @@ int orbm_fail(orbm_ctx *ctx, int code, const char *fmt, ...);
                              __FILE__, __LINE__);                                             \
     } while (0)
 
+int orbm_arena_alloc(orbm_ctx *ctx, size_t bytes, Arena *out);   // from the pool or hipMalloc
+void orbm_arena_release(orbm_ctx *ctx, Arena &a);                // to the pool or hipFree
 int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
+void *orbm_pin_up(orbm_ctx *ctx, size_t bytes);      // pinned upload staging of at least `bytes`, or null (too large / failed)
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
 int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
@@ -88,6 +102,9 @@ struct IoStage {
     orbm_ctx *ctx;
     bool dev;
     size_t used = 0;
+    size_t in_end = 0;        // [0, in_end) of the workspace holds inputs not yet copied to the device
+    bool in_sent = false;
+    size_t out_begin = 0;
     struct Out { void *host; void *devp; size_t bytes; };
     std::vector<Out> outs;
     IoStage(orbm_ctx *c, int io_on_device) : ctx(c), dev(io_on_device != 0) {}
@@ -95,6 +112,7 @@ struct IoStage {
     void *carve(size_t bytes);
     int in(const void *p, size_t bytes, const void **devp);          // copies host->device if needed
     int out(void *p, size_t bytes, void **devp);                     // registers device->host copy
+    int send_inputs();                                               // one H2D copy of everything in() staged
     int finish();                                                    // copies outputs back + sync (host mode)
 };
 

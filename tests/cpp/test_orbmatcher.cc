@@ -2,6 +2,7 @@
 // oracle.  The test generates flat arrays first, hands them to the oracle (orc_* in oracle/orb_oracle.cpp),
 // then builds the pointer graph (Frame / KeyFrame / MapPoint objects) from the same arrays, calls the class
 // (which runs on the GPU) and compares pointers, counts and side effects.  Run by tests/test_gpu_cpp_class.py.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -28,6 +29,7 @@ int orc_predict_scale(float max_distance, float current_dist, float log_scale_fa
 }
 
 static int g_fail = 0;
+static double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define EXPECT(c, ...) do { if (!(c)) { printf("FAIL %s:%d: %s  ", __FILE__, __LINE__, #c); printf(__VA_ARGS__); printf("\n"); g_fail++; } } while (0)
 
 static std::mt19937_64 rng(20161011);
@@ -168,6 +170,16 @@ static void TestBoW() {
             EXPECT(bad == 0, "KF-KF %d pointer mismatches", bad);
         }
     }
+    {   // per-call latency of the drop-in (snapshot + upload + kernel + download), warm
+        Raw ra = MakeRaw(2000, lm, 0, 1200, 100, 0.3, 0.85, 0.05, 0.1), rb = MakeRaw(2000, lm, 400, 1200, 100, 0.3, 0.8, 0.05, 0.1);
+        KeyFrame A; Frame F; FillKF(A, ra); FillFrame(F, rb);
+        ORBmatcher matcher(0.75f, true);
+        vector<MapPoint *> got;
+        matcher.SearchByBoW(&A, F, got);
+        double t0 = NowMs();
+        for (int r = 0; r < 20; r++) matcher.SearchByBoW(&A, F, got);
+        printf("latency SearchByBoW(KF,F) 2000x2000: %.3f ms per call\n", (NowMs() - t0) / 20);
+    }
     printf("SearchByBoW x2 done\n");
 }
 
@@ -267,6 +279,14 @@ static void TestProjPoints() {
         for (int i = 0; i < rf.n; i++) bad += G.mvpMapPoints[i] != (owner[i] >= 0 ? mps[owner[i]] : F.mvpMapPoints[i]);
         EXPECT(bad == 0, "proj %d slot mismatches", bad);
         EXPECT(want > 300, "proj too few matches (%d)", want);
+    }
+    {
+        ORBmatcher matcher(0.8f, true);
+        Frame G = F;
+        matcher.SearchByProjection(G, mps, 3.0f);
+        double t0 = NowMs();
+        for (int r = 0; r < 20; r++) { Frame H = F; matcher.SearchByProjection(H, mps, 3.0f); }
+        printf("latency SearchByProjection(F, 5000 MapPoints, th=3) into 1500 kp: %.3f ms per call\n", (NowMs() - t0) / 20);
     }
     printf("SearchByProjection(F, MapPoints) done\n");
 }
