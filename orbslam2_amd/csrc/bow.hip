@@ -65,23 +65,30 @@ __device__ __forceinline__ bool check_dist_epipolar_line(float x1, float y1, flo
 }
 
 // MODE 0: a7 (KF -> F), 1: a8 (KF -> KF), 2: a9 (triangulation)
-template <int MODE>
+// SPLIT = false: one workgroup per pair does everything (large batches: the chip is full anyway).
+// SPLIT = true : `splits` workgroups share a pair's nodes (a single SearchByBoW call would otherwise run on one CU);
+//                match rows are pre-set to -1 by the host side, histogram and count go to `pair_acc` (32 ints per pair)
+//                and bow_finish_kernel applies the rotation filter once all of them are done.
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                   const int32_t *__restrict__ fb, float ratio, int check_ori,
                                                   int only_stereo, const float *__restrict__ f12all,
                                                   const float *__restrict__ epiall, int stride,
-                                                  int32_t *__restrict__ match_all, int32_t *__restrict__ counts) {
+                                                  int32_t *__restrict__ match_all, int32_t *__restrict__ counts,
+                                                  int splits, int *__restrict__ pair_acc) {
     __shared__ uint32_t claimed[MAX_N / 32];  // bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
-    const int p = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = SPLIT ? (int)blockIdx.x / splits : (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int part = SPLIT ? (int)blockIdx.x - p * splits : 0;
+    const int nparts = SPLIT ? splits : 1;
     const FrameDev &A = table[fa[p]];
     const FrameDev &B = table[fb[p]];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
-    for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    if (!SPLIT) for (int i = tid; i < nOut; i += 256) match[i] = -1;
     if (MODE != 2)
         for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
     if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
     }
 
     int my_matches = 0;  // wave-uniform, counted on lane 0
-    for (int ia = wave; ia < A.n_nodes; ia += 4) {
+    for (int ia = part * 4 + wave; ia < A.n_nodes; ia += 4 * nparts) {
         const int ib = find_node(B.fv_node, B.n_nodes, A.fv_node[ia]);
         if (ib < 0) continue;
         const uint32_t offA = A.fv_off[ia], nA = A.fv_off[ia + 1] - offA;
@@ -231,6 +238,11 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
     }
     if (lane == 0 && my_matches) atomicAdd(&nmatches, my_matches);
     __syncthreads();
+    if (SPLIT) {
+        if (tid < ORBM_HISTO_LENGTH && hist[tid]) atomicAdd(&pair_acc[p * 32 + tid], hist[tid]);
+        if (tid == 0 && nmatches) atomicAdd(&pair_acc[p * 32 + 30], nmatches);
+        return;
+    }
     if (check_ori) {
         if (tid == 0) {
             int i1, i2, i3;
@@ -251,6 +263,46 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
         __syncthreads();
     }
     if (tid == 0) counts[p] = nmatches;
+}
+
+// rotation-consistency filter + count of a pair whose nodes were matched by several workgroups (:355-383 / :827-849 / :1062-1082)
+template <int MODE>
+__global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+                                                         const int32_t *__restrict__ fb, int check_ori, int stride,
+                                                         int32_t *__restrict__ match_all, int32_t *__restrict__ counts,
+                                                         const int *__restrict__ pair_acc) {
+    __shared__ int hist[ORBM_HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int removed_all;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const FrameDev &A = table[fa[p]];
+    const FrameDev &B = table[fb[p]];
+    const int nOut = MODE == 0 ? B.n : A.n;
+    const float *angB = MODE == 0 ? B.angle_raw : B.angle;
+    int32_t *match = match_all + (size_t)p * stride;
+    if (tid < ORBM_HISTO_LENGTH) hist[tid] = pair_acc[p * 32 + tid];
+    if (tid == 0) removed_all = 0;
+    __syncthreads();
+    if (check_ori) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        int removed = 0;
+        for (int i = tid; i < nOut; i += 256) {
+            const int m = match[i];
+            if (m < 0) continue;
+            const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
+            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+            if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }
+        }
+        if (removed) atomicAdd(&removed_all, removed);
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = pair_acc[p * 32 + 30] - removed_all;
 }
 
 int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, const int32_t *frame_b, float ratio,
@@ -284,13 +336,35 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         (rc = io.out(match, out_elems * 4, &dm)) || (rc = io.out(counts, (size_t)n_pairs * 4, &dc)))
         return rc;
     if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
-    dim3 grid(n_pairs), block(256);
+    // small batches: several workgroups per pair (about 1000 workgroups in all, at most 32 per pair)
+    const int splits = n_pairs >= 512 ? 1 : std::min(32, (1024 + n_pairs - 1) / n_pairs);
+    dim3 block(256);
+    if (splits == 1) {
+        dim3 grid(n_pairs);
 #define LAUNCH(M)                                                                                              \
-    hipLaunchKernelGGL(bow_kernel<M>, grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,        \
+    hipLaunchKernelGGL((bow_kernel<M, false>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,        \
                        (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
-                       stride, (int32_t *)dm, (int32_t *)dc)
-    if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
+                       stride, (int32_t *)dm, (int32_t *)dc, 1, (int *)nullptr)
+        if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
 #undef LAUNCH
+    } else {
+        rc = orbm_ws2_reserve(ctx, (size_t)n_pairs * 32 * sizeof(int));
+        if (rc) return rc;
+        int *acc = (int *)ctx->ws2;
+        HIPCHK(ctx, hipMemsetAsync(acc, 0, (size_t)n_pairs * 32 * sizeof(int), ctx->stream));
+        if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
+        dim3 grid(n_pairs * splits), fgrid(n_pairs);
+#define LAUNCH(M)                                                                                              \
+    do {                                                                                                       \
+        hipLaunchKernelGGL((bow_kernel<M, true>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,     \
+                           (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
+                           stride, (int32_t *)dm, (int32_t *)dc, splits, acc);                                  \
+        hipLaunchKernelGGL((bow_finish_kernel<M>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,   \
+                           (const int32_t *)dfb, check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);   \
+    } while (0)
+        if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
+#undef LAUNCH
+    }
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }

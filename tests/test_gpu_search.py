@@ -44,6 +44,35 @@ def test_bow_parity_pool(ctx, orc, variant, check_ori):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
+def test_bow_large_batch_uses_one_workgroup_per_pair(ctx, orc, variant):
+    """Batches of 512 pairs and more run one workgroup per pair (smaller ones split a pair's nodes over several
+    workgroups): same results either way."""
+    kfs = synth.keyframe_pool(seed=synth.SEED0 + 14, n_kf=6, n=600)
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.meshgrid(np.arange(6), np.arange(6))
+    pa, pb = np.resize(pa.ravel(), 540), np.resize(pb.ravel(), 540)
+    counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=600)
+    want = {}
+    for k, (i, j) in enumerate(zip(pa, pb)):
+        if (i, j) not in want:
+            want[(i, j)] = orc.search_bow(variant, kfs[i], kfs[j], 0.75, True)
+        wc, wm, _ = want[(i, j)]
+        assert counts[k] == wc and np.array_equal(match[k], wm), (k, i, j)
+    ctx.free_frames(ids)
+
+
+def test_triang_large_batch(ctx, orc):
+    c = synth.triang_pair(77, n=800)
+    ids = ctx.upload_frames(list(c[:2]))
+    P = 520
+    counts, match = ctx.search_triang(np.full(P, ids[0]), np.full(P, ids[1]), np.tile(c[2], (P, 1, 1)), np.tile(c[3], (P, 1)),
+                                      False, True, stride=800)
+    wc, wm, _ = orc.search_triang(c[0], c[1], c[2], c[3], False, True)
+    assert (counts == wc).all() and (match == wm[None, :]).all() and wc > 10
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
 def test_bow_parity_contended_claims(ctx, orc, variant):
     kfs = contended_pool(11 + variant, 5, 700, 150) + contended_pool(21, 2, 300, 10, n_nodes=2)  # nodes > 64 wide
     ids = ctx.upload_frames(kfs)
