@@ -16,11 +16,11 @@
 //   evaluate : every unresolved query walks its window in reference order against the current slot state
 //              and posts its chunk-local index with atomicMin on every slot it could still claim
 //              (distance <= acceptance threshold);
-//   decide   : a query is FINAL iff no lower-index unresolved query posted on any slot of its window;
-//              final queries apply their result to the slot state.
-// A query can only ever claim a slot it posted on, so a final query has seen the exact state the
-// sequential loop would have shown it; the lowest unresolved query is always final, so every round
-// makes progress.  Typical inputs need 2-4 rounds per chunk.
+//   decide   : a query is FINAL iff no lower-index unresolved query posted on its best (and, where a ratio test
+//              reads it, second-best) free slot; final queries apply their result to the slot state.
+// A query can only ever claim a slot it posted on and slots only ever become blocked, so the best / second-best
+// pair of a final query is the one the sequential loop would have found; the lowest unresolved query is always
+// final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
 #include <limits.h>
 #include <string.h>
 #include <algorithm>
@@ -488,7 +488,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         while (true) {
             uint32_t *post = (round & 1) ? post1 : post0;
             uint32_t *post_next = (round & 1) ? post0 : post1;
-            int bestDist = MODE == MODE_INIT ? INT_MAX : 256, bestDist2 = bestDist, bestIdx = -1;
+            int bestDist = MODE == MODE_INIT ? INT_MAX : 256, bestDist2 = bestDist, bestIdx = -1, bestIdx2 = -1;
             int bestLevel = -1, bestLevel2 = -1;
             // the reference's inner loop body for one candidate that passed the static gates
             auto consider = [&](int k, int oct, int dist) {
@@ -503,9 +503,9 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 if (dist < bestDist) {
                     bestDist2 = bestDist; bestDist = dist;
                     bestLevel2 = bestLevel; bestLevel = oct;
-                    bestIdx = k;
+                    bestIdx2 = bestIdx; bestIdx = k;
                 } else if (dist < bestDist2) {
-                    bestLevel2 = oct; bestDist2 = dist;
+                    bestLevel2 = oct; bestDist2 = dist; bestIdx2 = k;
                 }
             };
             // ---- evaluate ---------------------------------------------------------------------------
@@ -530,19 +530,13 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             __syncthreads();
             // ---- decide -----------------------------------------------------------------------------
             if (unresolved) {
+                // The outcome is a function of the best and (where a ratio test reads it) the second-best free candidate.
+                // Slots only ever become blocked, so it can change only if a lower-index unresolved query may still take
+                // one of those two; a best distance above the threshold can only get worse, so that is final at once.
                 bool is_final = true;
-                if (cached) {
-                    for (int i = 0; i < wave_ncand; i++) {
-                        const uint32_t v = cand_at(i);
-                        if (i < ncand && post[v & 0xFFFFu] < (uint32_t)tid) is_final = false;
-                    }
-                } else {
-                    auto chk = [&](int k, int oct, float) {
-                        if (MODE == MODE_SIM3) { if (oct < minL || oct > maxL) return; }
-                        if (post[k] < (uint32_t)tid) is_final = false;
-                    };
-                    if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, chk);
-                    else walk_window<false>(acc, x, y, r, minL, maxL, chk);
+                if (bestIdx >= 0 && bestDist <= thr) {
+                    if (post[bestIdx] < (uint32_t)tid) is_final = false;
+                    if ((MODE == MODE_PROJ || MODE == MODE_INIT) && bestIdx2 >= 0 && post[bestIdx2] < (uint32_t)tid) is_final = false;
                 }
                 if (is_final) {
                     unresolved = false;
@@ -779,15 +773,15 @@ int g_win_variant = 0;
 
 template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
-    // MODE_INIT: one window size, hundreds of candidates; frames too large for collect_kernel's LDS staging
-    const bool single = MODE == MODE_INIT || g_win_variant != 0 ||
+    // frames too large for collect_kernel's LDS staging use the single-kernel form
+    const bool single = g_win_variant != 0 ||
                         (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + COST_CLASSES) * 4 > 160 * 1024;
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
             return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr, WIN_CACHE);
         return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, nullptr, WIN_CACHE);
     }
-    if (MODE != MODE_INIT) {
+    {
         const int waves_per_inst = (max_q + 63) / 64;
         if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr, nullptr, WIN_CACHE);
         const size_t rows = (size_t)n_inst * waves_per_inst;
