@@ -175,13 +175,18 @@ __device__ __forceinline__ int pos_in_grid(const FrameDev &f, int i) {
     return posX * ORBM_GRID_ROWS + posY;
 }
 
+constexpr int GRID_LDS_MAX_N = 8192;   // keypoint lists up to this size are ordered in LDS
+
 __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restrict__ table,
                                                          const int32_t *__restrict__ ids) {
     __shared__ uint32_t cnt[ORBM_GRID_CELLS];
+    __shared__ uint32_t off[ORBM_GRID_CELLS + 1];
     __shared__ uint32_t part[256];
+    __shared__ uint16_t lidx[GRID_LDS_MAX_N];
     const FrameDev &f = table[ids[blockIdx.x]];
     const int tid = threadIdx.x;
     const int n = f.n;
+    const bool in_lds = n <= GRID_LDS_MAX_N;
     for (int c = tid; c < ORBM_GRID_CELLS; c += 256) cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
@@ -189,47 +194,66 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
         if (c >= 0) atomicAdd(&cnt[c], 1u);
     }
     __syncthreads();
-    // exclusive scan: 12 consecutive cells per thread
+    // exclusive scan: 12 consecutive cells per thread, then a wave scan of the 256 partial sums
     constexpr int PER = ORBM_GRID_CELLS / 256;
     uint32_t loc[PER];
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) { loc[k] = s; s += cnt[tid * PER + k]; }
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 256; t++) { uint32_t v = part[t]; part[t] = run; run += v; }
-        f.cell_off[ORBM_GRID_CELLS] = run;
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += up;
     }
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
     __syncthreads();
-    const uint32_t base = part[tid];
+    uint32_t base = incl - s;
+    for (int w = 0; w < (tid >> 6); w++) base += part[w];
+    if (tid == 255) { off[ORBM_GRID_CELLS] = base + s; f.cell_off[ORBM_GRID_CELLS] = base + s; }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const uint32_t o = base + loc[k];
+        off[tid * PER + k] = o;
         f.cell_off[tid * PER + k] = o;
         cnt[tid * PER + k] = o;  // becomes the scatter cursor
     }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         const int c = pos_in_grid(f, i);
-        if (c >= 0) f.cell_idx[atomicAdd(&cnt[c], 1u)] = (uint32_t)i;
+        if (c < 0) continue;
+        const uint32_t at = atomicAdd(&cnt[c], 1u);
+        if (in_lds) lidx[at] = (uint16_t)i; else f.cell_idx[at] = (uint32_t)i;
     }
     __syncthreads();
-    __threadfence_block();
+    if (!in_lds) __threadfence_block();
     // ascending order inside each cell (lists are short: ~0.65 keypoints per cell at n=2000)
     for (int c = tid; c < ORBM_GRID_CELLS; c += 256) {
-        const uint32_t b = f.cell_off[c], e = cnt[c];
-        for (uint32_t i = b + 1; i < e; i++) {
-            const uint32_t v = f.cell_idx[i];
-            uint32_t j = i;
-            while (j > b && f.cell_idx[j - 1] > v) { f.cell_idx[j] = f.cell_idx[j - 1]; j--; }
-            f.cell_idx[j] = v;
+        const uint32_t b = off[c], e = cnt[c];
+        if (in_lds) {
+            for (uint32_t i = b + 1; i < e; i++) {
+                const uint16_t v = lidx[i];
+                uint32_t j = i;
+                while (j > b && lidx[j - 1] > v) { lidx[j] = lidx[j - 1]; j--; }
+                lidx[j] = v;
+            }
+        } else {
+            for (uint32_t i = b + 1; i < e; i++) {
+                const uint32_t v = f.cell_idx[i];
+                uint32_t j = i;
+                while (j > b && f.cell_idx[j - 1] > v) { f.cell_idx[j] = f.cell_idx[j - 1]; j--; }
+                f.cell_idx[j] = v;
+            }
         }
-        for (uint32_t i = b; i < e; i++) {
-            const uint32_t k = f.cell_idx[i];
-            f.cell_rec[i] = make_float4(f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16)));
-        }
+    }
+    __syncthreads();
+    if (!in_lds) __threadfence_block();
+    // cell-ordered records, one per list position (independent loads)
+    const uint32_t total = off[ORBM_GRID_CELLS];
+    for (uint32_t i = tid; i < total; i += 256) {
+        const uint32_t k = in_lds ? (uint32_t)lidx[i] : f.cell_idx[i];
+        if (in_lds) f.cell_idx[i] = k;
+        f.cell_rec[i] = make_float4(f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16)));
     }
 }
 

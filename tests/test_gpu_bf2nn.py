@@ -20,7 +20,7 @@ def test_hamming_pairs_matches_swar(ctx, orc):
     assert got[:10].max() == 0 and got[10:20].min() == 256
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 1000, 2000])
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 2000, 8192, 9000])   # above 8192 the lists are ordered in global memory
 def test_grid_build_matches_oracle(ctx, orc, n):
     rng = np.random.default_rng(100 + n)
     lm = synth.random_descriptors(rng, max(n, 1))
