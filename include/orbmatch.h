@@ -143,6 +143,16 @@ int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
 int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist,
                           int io_on_device);
 
+/* ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:363-449), batched over map points.
+ * Point p owns descriptors desc[32*off[p] .. 32*off[p+1]) (the rows of its non-bad observing keyframes, in the
+ * order the reference's map iteration yields them).  best_idx[p] = index, within the point's own list, of the
+ * descriptor with the least median Hamming distance to all of them (median = element (int)(0.5*(N-1)) of the sorted
+ * row, first row wins ties), or -1 for an empty list (the reference returns without touching mDescriptor).  The
+ * caller then sets mDescriptor = that row.  Replaces the per-point calls at LocalMapping.cc:289,780,926,
+ * LoopClosing.cc:918, Tracking.cc:673,864,1461.  Limit: 512 observations per point (ORBM_ELIMIT beyond). */
+int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_t *off, const uint8_t *desc,
+                                       int32_t *best_idx, int io_on_device);
+
 /* ---- BASELINE config 2: brute-force 2-NN + threshold + ratio test over keyframe pairs --------
  * For pair p and every row i of frame_a[p]: scan all rows j of frame_b[p] in ascending j with the
  * strict-< best / second-best update of ORBmatcher.cc:290-300, accept iff best <= th and

@@ -48,6 +48,7 @@ def lib():
         L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
         L.orc_search_window_free.argtypes = [FV, WQ, C.c_int, C.c_int, i32p, u64p]
         L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
+        L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         _lib = L
     return _lib
@@ -162,6 +163,11 @@ def search_init(f1, f2, prev_xy, window, ratio, check_ori):
     cnt = lib().orc_search_init(C.byref(v1), C.byref(v2), _p(prev, C.c_float), window, ratio, int(check_ori),
                                 _p(m12, C.c_int32), C.byref(ncmp))
     return int(cnt), m12[:f1.n], prev, int(ncmp.value)
+
+
+def distinctive_descriptor(desc) -> int:
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    return int(lib().orc_distinctive_descriptor(_p(d, C.c_uint8) if len(d) else None, len(d)))
 
 
 def predict_scale(max_distance, current_dist, log_scale_factor, n_levels) -> int:

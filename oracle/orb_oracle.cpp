@@ -604,6 +604,33 @@ int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float 
     return nmatches;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:408-441: index of the chosen descriptor among n rows
+int orc_distinctive_descriptor(const uint8_t *desc, int n) {
+    if (n <= 0) return -1;                                              // :405-406
+    const size_t N = (size_t)n;
+    std::vector<float> Distances(N * N);                                // float Distances[N][N]  (:412)
+    for (size_t i = 0; i < N; i++) {
+        Distances[i * N + i] = 0;
+        for (size_t j = i + 1; j < N; j++) {
+            int distij = orc_hamming256(desc + 32 * i, desc + 32 * j);
+            Distances[i * N + j] = distij;
+            Distances[j * N + i] = distij;
+        }
+    }
+    int BestMedian = INT_MAX;
+    int BestIdx = 0;
+    for (size_t i = 0; i < N; i++) {
+        std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+        std::sort(vDists.begin(), vDists.end());
+        int median = vDists[0.5 * (N - 1)];                             // :434
+        if (median < BestMedian) {
+            BestMedian = median;
+            BestIdx = (int)i;
+        }
+    }
+    return BestIdx;
+}
+
 // MapPoint.cc:569-602 (PredictScale) in flat form: host-side helper of the a11 gates.  MapPoint.cc sees
 // `using namespace std` through the DBoW2 headers, so log(float)/ceil(float) resolve to the float overloads.
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels) {

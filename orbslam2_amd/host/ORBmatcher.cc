@@ -645,4 +645,33 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     return nFused;
 }
 
+// ---- MapPoint.cc:363-449, batched -------------------------------------------------------------------------------------
+void ComputeDistinctiveDescriptorsBatch(const vector<MapPoint *> &vpMapPoints) {
+    const int P = (int)vpMapPoints.size();
+    if (P == 0) return;
+    vector<int32_t> off(P + 1, 0);
+    vector<uint8_t> desc;
+    vector<const uint8_t *> rows;                 // source row of every gathered descriptor
+    for (int p = 0; p < P; p++) {
+        MapPoint *pMP = vpMapPoints[p];
+        if (pMP && !pMP->isBad())                                                         // :375-376
+            for (auto mit = pMP->mObservations.begin(), mend = pMP->mObservations.end(); mit != mend; mit++) {
+                KeyFrame *pKF = mit->first;
+                if (!pKF->isBad()) rows.push_back(pKF->mDescriptors.ptr<uint8_t>((int)mit->second));   // :397-398
+            }
+        off[p + 1] = (int32_t)rows.size();
+    }
+    desc.resize(rows.size() * 32);
+    for (size_t i = 0; i < rows.size(); i++) memcpy(&desc[i * 32], rows[i], 32);
+    vector<int32_t> best(P, -1);
+    Check(orbm_distinctive_descriptors_batch(Ctx(), P, off.data(), desc.empty() ? nullptr : desc.data(), best.data(), 0),
+          "orbm_distinctive_descriptors_batch");
+    for (int p = 0; p < P; p++)
+        if (best[p] >= 0) {                                                               // empty list: mDescriptor untouched (:405-406)
+            cv::Mat d(1, 32, CV_8U);
+            memcpy(d.ptr<uint8_t>(), rows[off[p] + best[p]], 32);
+            vpMapPoints[p]->mDescriptor = d;                                              // :447
+        }
+}
+
 }  // namespace ORB_SLAM2

@@ -118,6 +118,8 @@ public:
     cv::Mat GetRotation() { return Rcw.clone(); }       // 3x3 CV_32F
     cv::Mat GetTranslation() { return tcw.clone(); }    // 3x1
     cv::Mat GetCameraCenter() { return Ow.clone(); }    // 3x1
+    bool isBad() { return mbBad; }                          // KeyFrame.cc:703
+    bool mbBad = false;
     bool IsInImage(const float &x, const float &y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
 
     std::vector<MapPoint *> mvpMapPoints;

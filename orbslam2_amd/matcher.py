@@ -133,6 +133,16 @@ class Context:
         self._chk(self._L.orbm_hamming256_pairs(self._h, a.shape[0], _addr(a), _addr(b), _addr(out), 0))
         return out[: a.shape[0]]
 
+    # ---- MapPoint::ComputeDistinctiveDescriptors, batched ----
+    def distinctive_descriptors(self, off: np.ndarray, desc: np.ndarray) -> np.ndarray:
+        off = np.ascontiguousarray(off, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(off) - 1
+        out = np.full(max(n, 1), -1, np.int32)
+        self._chk(self._L.orbm_distinctive_descriptors_batch(self._h, n, _addr(off), _addr(desc) if len(desc) else None,
+                                                             _addr(out), 0))
+        return out[:n]
+
     # ---- config 2 ----
     def bf2nn(self, fa, fb, ratio: float, th: int, stride: int, want_dist: bool = True):
         fa = np.ascontiguousarray(fa, np.int32)

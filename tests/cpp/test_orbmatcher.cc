@@ -25,6 +25,7 @@ int orc_search_proj_points(const orbm_frame_view *F, const orbm_proj_queries *Q,
 int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int check_ori, const uint8_t *slot_flags, int32_t *owner, uint64_t *ncmp);
 int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int chi2_gate, int32_t *best_idx, uint64_t *ncmp);
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize, float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp);
+int orc_distinctive_descriptor(const uint8_t *desc, int n);
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels);
 }
 
@@ -613,6 +614,41 @@ static void TestFuse() {
     printf("Fuse x2 done\n");
 }
 
+static void TestDistinctive() {
+    vector<Desc> lm(400); for (auto &d : lm) d = RandDesc();
+    // 12 keyframes (two of them bad), 400 map points observed by 0..12 of them
+    vector<std::unique_ptr<KeyFrame>> kfs;
+    for (int k = 0; k < 12; k++) {
+        kfs.emplace_back(new KeyFrame());
+        KeyFrame &K = *kfs.back();
+        K.N = 400; K.mDescriptors = cv::Mat(400, 32, CV_8U); K.mvuRight.assign(400, -1.f); K.mvpMapPoints.assign(400, nullptr);
+        K.mbBad = (k == 3 || k == 7);
+        for (int i = 0; i < 400; i++) { Desc d = Observe(lm[i], 0.08); memcpy(K.mDescriptors.ptr<uint8_t>(i), d.b, 32); }
+    }
+    vector<MapPoint *> pts;
+    vector<int> want;
+    vector<Desc> before;
+    for (int i = 0; i < 400; i++) {
+        MapPoint *p = NewMP(ORBM_MP_PRESENT | (i % 37 == 5 ? ORBM_MP_BAD : 0), &lm[i]);
+        vector<Desc> rows;
+        if (i % 41 != 0)
+            for (int k = 0; k < 12; k++) if (U(0, 1) < 0.6) p->mObservations[kfs[k].get()] = i;
+        // expected: the reference's gather order is the std::map order (keyframe pointer order), bad keyframes skipped
+        for (auto &kv : p->mObservations) if (!kv.first->mbBad) { Desc d; memcpy(d.b, kv.first->mDescriptors.ptr<uint8_t>((int)kv.second), 32); rows.push_back(d); }
+        Desc chosen = lm[i];
+        if (!p->mbBad && !rows.empty()) chosen = rows[orc_distinctive_descriptor(rows[0].b, (int)rows.size())];
+        before.push_back(chosen);
+        pts.push_back(p);
+    }
+    pts.push_back(nullptr);
+    ComputeDistinctiveDescriptorsBatch(pts);
+    int bad = 0, changed = 0;
+    for (int i = 0; i < 400; i++) { bad += memcmp(pts[i]->mDescriptor.ptr<uint8_t>(), before[i].b, 32) != 0; changed += memcmp(before[i].b, lm[i].b, 32) != 0; }
+    EXPECT(bad == 0, "distinctive descriptors: %d mismatches", bad);
+    EXPECT(changed > 300, "distinctive descriptors: only %d points got a new descriptor", changed);
+    printf("ComputeDistinctiveDescriptorsBatch done\n");
+}
+
 int main() {
     try {
         // a1 helper
@@ -627,6 +663,7 @@ int main() {
         TestWindowOverloads();
         TestSim3();
         TestFuse();
+        TestDistinctive();
     } catch (const std::exception &e) {
         printf("EXCEPTION: %s\n", e.what());
         return 2;

@@ -294,3 +294,24 @@ def test_window_free_parity(ctx, orc, chi2, dist_th, stereo):
         tot += (wb >= 0).sum()
     assert tot > 200
     ctx.free_frames(fids); ctx.free_queries(qids)
+
+
+def test_distinctive_descriptors_parity(ctx, orc):
+    """MapPoint::ComputeDistinctiveDescriptors batched over map points: empty lists, single observations, ties
+    (identical descriptors), lists above one wavefront, the 512-observation limit."""
+    from orbslam2_amd.matcher import OrbmError
+    rng = np.random.default_rng(77)
+    sizes = [0, 1, 2, 3, 5, 8, 64, 65, 130, 512] + list(rng.integers(1, 40, 400))
+    descs, off = [], [0]
+    for n in sizes:
+        lm = synth.random_descriptors(rng, 1)[0]
+        d = np.stack([synth.observe(rng, lm[None, :], 0.08)[0] for _ in range(n)]) if n else np.zeros((0, 32), np.uint8)
+        if n >= 3 and rng.random() < 0.3:
+            d[rng.integers(0, n)] = d[0]          # exact duplicates: equal medians, first wins
+        descs.append(d); off.append(off[-1] + n)
+    got = ctx.distinctive_descriptors(np.array(off), np.concatenate(descs))
+    want = np.array([orc.distinctive_descriptor(d) for d in descs])
+    assert np.array_equal(got, want)
+    assert (want[10:] >= 0).all() and len(set(want[10:])) > 5
+    with pytest.raises(OrbmError):
+        ctx.distinctive_descriptors(np.array([0, 513]), np.zeros((513, 32), np.uint8))

@@ -201,3 +201,16 @@ def test_predict_scale_known_answers(orc):
     assert orc.predict_scale(10.0, 100.0, lsf, 8) == 0          # negative -> clamped to 0
     assert orc.predict_scale(10.0, 10.0 / 1.2 ** 2.5, lsf, 8) == 3
     assert orc.predict_scale(10.0, 0.001, lsf, 8) == 7          # clamped to levels-1
+
+
+def test_distinctive_descriptor_known_answers(orc):
+    """MapPoint.cc:408-441 by hand: a = 0...0, b = one bit, c = all ones -> rows sorted [0,1,256], [0,1,255],
+    [0,255,256]; median index (int)(0.5*2) = 1 -> medians 1, 1, 255 -> first minimum = row 0."""
+    a = np.zeros(32, np.uint8); b = a.copy(); b[0] = 1; c = np.full(32, 255, np.uint8)
+    assert orc.distinctive_descriptor(np.stack([a, b, c])) == 0
+    assert orc.distinctive_descriptor(np.stack([c, b, a])) == 1      # medians 255, 1, 1 -> row 1
+    assert orc.distinctive_descriptor(np.stack([c, a])) == 0         # N = 2: median index 0 -> self distance 0 for both
+    assert orc.distinctive_descriptor(np.stack([c])) == 0
+    assert orc.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
+    # N = 4, median index (int)1.5 = 1: rows of {a, a, b, c}: a: [0,0,1,256] -> 0; b: [0,1,1,255] -> 1; c -> 255
+    assert orc.distinctive_descriptor(np.stack([b, c, a, a])) == 2
