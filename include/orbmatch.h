@@ -143,6 +143,20 @@ int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
 int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist,
                           int io_on_device);
 
+/* ---- descriptor stage of Frame::ComputeStereoMatches (Frame.cc:632-728), batched over stereo
+ * frames.  frame_left / frame_right are uploaded views whose x, y, octave, desc are mvKeys / mvKeysRight and
+ * mDescriptors / mDescriptorsRight (raw, not undistorted, coordinates); scale_factors as in the frame.
+ * max_disparity[p] = mbf / mb (:664-666).  For left keypoint iL of pair p:
+ *   best_dist[p*stride+iL] = least Hamming distance below TH_HIGH (100 when none), best_idx_r[...] = that right
+ *   keypoint or -1; candidates = right keypoints whose row band [floor(y-2*sf), ceil(y+2*sf)] holds row (int)vL,
+ *   octave within +-1, uL - max_disparity <= uR <= uL, ascending index, strict '<'.
+ * Rows beyond stride / left n are untouched.  The caller continues with :734 (SAD refinement) where
+ * best_dist < (TH_HIGH+TH_LOW)/2.  Row bands reaching outside the image are undefined behaviour in the reference;
+ * here they simply never match a row that does not exist. */
+int orbm_stereo_match_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_left, const int32_t *frame_right,
+                            const float *max_disparity, int32_t stride, int32_t *best_idx_r, int32_t *best_dist,
+                            int io_on_device);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:363-449), batched over map points.
  * Point p owns descriptors desc[32*off[p] .. 32*off[p+1]) (the rows of its non-bad observing keyframes, in the
  * order the reference's map iteration yields them).  best_idx[p] = index, within the point's own list, of the

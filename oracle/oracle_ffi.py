@@ -48,6 +48,7 @@ def lib():
         L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
         L.orc_search_window_free.argtypes = [FV, WQ, C.c_int, C.c_int, i32p, u64p]
         L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
+        L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
         L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         _lib = L
@@ -163,6 +164,15 @@ def search_init(f1, f2, prev_xy, window, ratio, check_ori):
     cnt = lib().orc_search_init(C.byref(v1), C.byref(v2), _p(prev, C.c_float), window, ratio, int(check_ori),
                                 _p(m12, C.c_int32), C.byref(ncmp))
     return int(cnt), m12[:f1.n], prev, int(ncmp.value)
+
+
+def stereo_match(left, right, n_rows, max_d):
+    idx = np.zeros(max(left.n, 1), np.int32)
+    dist = np.zeros(max(left.n, 1), np.int32)
+    ncmp = C.c_uint64(0)
+    vl, vr = left.view(), right.view()
+    lib().orc_stereo_match(C.byref(vl), C.byref(vr), n_rows, max_d, _p(idx, C.c_int32), _p(dist, C.c_int32), C.byref(ncmp))
+    return idx[:left.n], dist[:left.n], int(ncmp.value)
 
 
 def distinctive_descriptor(desc) -> int:

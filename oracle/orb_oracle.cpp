@@ -604,6 +604,58 @@ int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float 
     return nmatches;
 }
 
+// Frame::ComputeStereoMatches, Frame.cc:632-728 (row table + descriptor stage; the SAD refinement is image-domain).
+// L / R carry mvKeys / mvKeysRight in x, y, octave.  n_rows = mvImagePyramid[0].rows.  Row bands are clipped to the
+// table (the reference indexes out of bounds there).
+int orc_stereo_match(const orbm_frame_view *L, const orbm_frame_view *R, int n_rows, float max_d, int32_t *best_idx_r,
+                     int32_t *best_dist, uint64_t *ncmp) {
+    Counter cnt;
+    std::vector<std::vector<size_t>> vRowIndices(n_rows, std::vector<size_t>());
+    const int Nr = R->n;
+    for (int iR = 0; iR < Nr; iR++) {
+        const float kpY = R->y[iR];
+        const float r = 2.0f * R->scale_factors[R->octave[iR]];
+        const int maxr = (int)ceilf(kpY + r);
+        const int minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < n_rows) vRowIndices[yi].push_back(iR);
+    }
+    const float minD = 0;
+    const float maxD = max_d;
+    for (int iL = 0; iL < L->n; iL++) {
+        best_idx_r[iL] = -1;
+        best_dist[iL] = ORBM_TH_HIGH;
+        const int levelL = L->octave[iL];
+        const float vL = L->y[iL];
+        const float uL = L->x[iL];
+        if (!(vL >= 0) || (size_t)vL >= (size_t)n_rows) continue;
+        const std::vector<size_t> &vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = ORBM_TH_HIGH;
+        int bestIdxR = -1;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            if (R->octave[iR] < levelL - 1 || R->octave[iR] > levelL + 1) continue;
+            const float uR = R->x[iR];
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming256(L->desc + 32 * (size_t)iL, R->desc + 32 * iR);
+                cnt.n++;
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = (int)iR;
+                }
+            }
+        }
+        best_idx_r[iL] = bestIdxR;
+        best_dist[iL] = bestDist;
+    }
+    if (ncmp) *ncmp = cnt.n;
+    return 0;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:408-441: index of the chosen descriptor among n rows
 int orc_distinctive_descriptor(const uint8_t *desc, int n) {
     if (n <= 0) return -1;                                              // :405-406

@@ -13,7 +13,7 @@ SYMBOLS = [
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_set_stream", "orbm_synchronize", "orbm_device_info",
     "orbm_frames_upload", "orbm_frames_free", "orbm_frame_set_mp_flags", "orbm_frame_grid_download",
     "orbm_proj_queries_upload", "orbm_win_queries_upload", "orbm_queries_free",
-    "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
+    "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_stereo_match_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
     "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
     "orbm_popcount_peak",
 ]
@@ -50,6 +50,7 @@ def load():
     L.orbm_queries_free.argtypes = [vp, C.c_int, vp]
     L.orbm_hamming256_pairs.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
     L.orbm_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+    L.orbm_stereo_match_batch.argtypes = [vp, C.c_int, vp, vp, vp, i32, vp, vp, C.c_int]
     L.orbm_bf2nn_batch.argtypes = [vp, C.c_int, vp, vp, f32, C.c_int, i32, vp, vp, vp, vp, C.c_int]
     L.orbm_search_bow_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, f32, C.c_int, i32, vp, vp, C.c_int]
     L.orbm_search_triang_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, i32, vp, vp, C.c_int]

@@ -1,0 +1,112 @@
+// stereo.hip -- descriptor stage of Frame::ComputeStereoMatches (Frame.cc:632-728), batched over stereo frames:
+// for every left keypoint the right keypoint with the least Hamming distance among those whose row band covers the
+// left keypoint's row (Frame.cc:645-660), whose octave is within +-1 (:712) and whose x lies in [uL - maxD, uL]
+// (:690-717); strict '<' against an initial TH_HIGH, candidates in ascending right index (the order the row table
+// yields them).  The SAD sub-pixel refinement that follows (:734-833) works on the image pyramid and stays with
+// the caller.
+//
+// The row table is not materialised: membership is two integer compares, so every left keypoint (one per lane)
+// scans ALL right keypoints, staged through LDS 256 at a time and read as broadcasts, in ascending index order.
+#include "orbm_internal.h"
+
+namespace {
+
+constexpr int ST_TILE = 256;
+
+__global__ __launch_bounds__(256) void stereo_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fl,
+                                                     const int32_t *__restrict__ fr, const float *__restrict__ max_d,
+                                                     int blocks_per_pair, int stride, int32_t *__restrict__ best_idx,
+                                                     int32_t *__restrict__ best_dist) {
+    __shared__ uint4 s_desc[2 * ST_TILE];
+    __shared__ float s_x[ST_TILE];
+    __shared__ int s_minr[ST_TILE], s_maxr[ST_TILE], s_oct[ST_TILE];
+    const int p = blockIdx.x / blocks_per_pair;
+    const int iL = (blockIdx.x - p * blocks_per_pair) * 256 + (int)threadIdx.x;
+    const FrameDev &L = table[fl[p]];
+    const FrameDev &R = table[fr[p]];
+    const int tid = threadIdx.x;
+    const bool have = iL < L.n;
+    uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float uL = 0.f, minU = 0.f;
+    int row = 0, levelL = 0;
+    bool live = false;
+    if (have) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(L.desc) + 2 * (size_t)iL;
+        const uint4 lo = g[0], hi = g[1];
+        q[0] = lo.x; q[1] = lo.y; q[2] = lo.z; q[3] = lo.w; q[4] = hi.x; q[5] = hi.y; q[6] = hi.z; q[7] = hi.w;
+        uL = L.x[iL];
+        row = (int)L.y[iL];                                   // vRowIndices[vL]: float -> index truncation (:684)
+        levelL = L.octave[iL];
+        minU = __fsub_rn(uL, max_d[p]);                       // :690
+        live = !(uL < 0);                                     // maxU = uL - 0 (:691-694)
+    }
+    int bestDist = ORBM_TH_HIGH, bestIdxR = -1;               // :696
+    for (int base = 0; base < R.n; base += ST_TILE) {
+        __syncthreads();
+        const int j = base + tid;
+        if (j < R.n) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(R.desc) + 2 * (size_t)j;
+            s_desc[2 * tid] = g[0]; s_desc[2 * tid + 1] = g[1];
+            const float kpY = R.y[j];
+            const int o = R.octave[j];
+            const float r = __fmul_rn(2.0f, R.sf[o]);         // :654
+            s_x[tid] = R.x[j];
+            s_maxr[tid] = (int)ceilf(__fadd_rn(kpY, r));      // :655
+            s_minr[tid] = (int)floorf(__fsub_rn(kpY, r));     // :656
+            s_oct[tid] = o;
+        }
+        __syncthreads();
+        const int cnt = min(ST_TILE, R.n - base);
+        for (int c = 0; c < cnt; c++) {
+            const uint4 lo = s_desc[2 * c], hi = s_desc[2 * c + 1];
+            const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int dist = (int)hamming256(q, cd);
+            const float uR = s_x[c];
+            const int o = s_oct[c];
+            const bool ok = live && row >= s_minr[c] && row <= s_maxr[c] &&          // row band (:658-659)
+                            !(o < levelL - 1 || o > levelL + 1) &&                     // :712
+                            uR >= minU && uR <= uL;                                    // :717
+            if (ok && dist < bestDist) { bestDist = dist; bestIdxR = base + c; }      // :722-726
+        }
+    }
+    if (have) {
+        best_idx[(size_t)p * stride + iL] = bestIdxR;
+        best_dist[(size_t)p * stride + iL] = bestDist;
+    }
+}
+
+}  // namespace
+
+extern "C" int orbm_stereo_match_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_left, const int32_t *frame_right,
+                                       const float *max_disparity, int32_t stride, int32_t *best_idx_r, int32_t *best_dist,
+                                       int io_on_device) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_pairs < 0 || (n_pairs > 0 && (!frame_left || !frame_right || !max_disparity || !best_idx_r || !best_dist)) || stride < 0)
+        return orbm_fail(ctx, ORBM_EINVAL, "stereo_match_batch: null argument or negative size");
+    if (n_pairs == 0 || stride == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!io_on_device) {
+        int rc = orbm_check_frames(ctx, n_pairs, frame_left, "frame_left");
+        if (!rc) rc = orbm_check_frames(ctx, n_pairs, frame_right, "frame_right");
+        if (rc) return rc;
+        for (int p = 0; p < n_pairs; p++)
+            if (ctx->h_frames[frame_left[p]].n > stride)
+                return orbm_fail(ctx, ORBM_EINVAL, "stereo_match_batch: stride %d < %d left keypoints of pair %d", stride, ctx->h_frames[frame_left[p]].n, p);
+        rc = orbm_ws_reserve(ctx, (size_t)n_pairs * 12 + (size_t)n_pairs * stride * 8 + 4096);
+        if (rc) return rc;
+    }
+    const size_t out_elems = (size_t)n_pairs * stride;
+    IoStage io(ctx, io_on_device);
+    const void *dl, *dr, *dm; void *di, *dd;
+    int rc;
+    if ((rc = io.in(frame_left, (size_t)n_pairs * 4, &dl)) || (rc = io.in(frame_right, (size_t)n_pairs * 4, &dr)) ||
+        (rc = io.in(max_disparity, (size_t)n_pairs * 4, &dm)) || (rc = io.out(best_idx_r, out_elems * 4, &di)) ||
+        (rc = io.out(best_dist, out_elems * 4, &dd)))
+        return rc;
+    const int blocks_per_pair = (stride + 255) / 256;
+    hipLaunchKernelGGL(stereo_kernel, dim3((unsigned)(n_pairs * blocks_per_pair)), dim3(256), 0, ctx->stream, ctx->d_frames,
+                       (const int32_t *)dl, (const int32_t *)dr, (const float *)dm, blocks_per_pair, stride, (int32_t *)di,
+                       (int32_t *)dd);
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
+}

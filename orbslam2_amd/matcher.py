@@ -143,6 +143,17 @@ class Context:
                                                              _addr(out), 0))
         return out[:n]
 
+    # ---- descriptor stage of Frame::ComputeStereoMatches, batched ----
+    def stereo_match(self, left, right, max_disparity, stride: int):
+        fl = np.ascontiguousarray(left, np.int32)
+        fr = np.ascontiguousarray(right, np.int32)
+        md = np.ascontiguousarray(max_disparity, np.float32)
+        p = len(fl)
+        idx = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        dist = np.full((max(p, 1), max(stride, 1)), 100, np.int32)
+        self._chk(self._L.orbm_stereo_match_batch(self._h, p, _addr(fl), _addr(fr), _addr(md), stride, _addr(idx), _addr(dist), 0))
+        return idx[:p], dist[:p]
+
     # ---- config 2 ----
     def bf2nn(self, fa, fb, ratio: float, th: int, stride: int, want_dist: bool = True):
         fa = np.ascontiguousarray(fa, np.int32)

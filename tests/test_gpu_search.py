@@ -315,3 +315,45 @@ def test_distinctive_descriptors_parity(ctx, orc):
     assert (want[10:] >= 0).all() and len(set(want[10:])) > 5
     with pytest.raises(OrbmError):
         ctx.distinctive_descriptors(np.array([0, 513]), np.zeros((513, 32), np.uint8))
+
+
+def test_stereo_match_parity(ctx, orc):
+    """Descriptor stage of Frame::ComputeStereoMatches: rectified stereo pair (same rows +- a pixel or two, disparity
+    0..60), octaves +-1, some left keypoints with negative x, empty right frame."""
+    rng = np.random.default_rng(88)
+    pairs = []
+    for n in (1500, 300, 64):
+        lm = synth.random_descriptors(rng, n)
+        xl = rng.uniform(16, 624, n).astype(np.float32); yl = rng.uniform(16, 464, n).astype(np.float32)
+        octl = synth.octaves_level_major(n)
+        left = synth.make_frame(rng, lm, np.arange(n), x=xl, y=yl, octave=octl, with_fv=False)
+        keep = rng.random(n) < 0.8                       # 80 % of the landmarks are seen by the right camera
+        m = int(keep.sum())
+        disp = rng.uniform(-2, 60, m).astype(np.float32)
+        xr = (xl[keep] - disp).astype(np.float32); yr = (yl[keep] + rng.normal(0, 1.2, m)).astype(np.float32)
+        octr = np.clip(octl[keep] + rng.integers(-2, 3, m), 0, 7).astype(octl.dtype)
+        extra = n // 3                                   # unrelated right keypoints
+        lm2 = synth.random_descriptors(rng, extra)
+        right_lm = np.concatenate([lm[keep], lm2])
+        right = synth.make_frame(rng, right_lm, np.arange(m + extra),
+                                 x=np.concatenate([xr, rng.uniform(16, 624, extra).astype(np.float32)]),
+                                 y=np.concatenate([yr, rng.uniform(16, 464, extra).astype(np.float32)]),
+                                 octave=np.concatenate([octr, synth.octaves_level_major(extra)]), with_fv=False)
+        perm = rng.permutation(right.n)                  # right keypoints in extractor order, not left order
+        right = synth.make_frame(rng, right.desc[perm], np.arange(right.n), x=right.x[perm], y=right.y[perm], octave=right.octave[perm],
+                                 p_flip=0.0, with_fv=False)
+        left.x[:3] = -1.0                                # maxU < 0 (:693)
+        pairs.append((left, right))
+    empty = synth.make_frame(rng, synth.random_descriptors(rng, 1), np.arange(0), with_fv=False)
+    pairs.append((pairs[1][0], empty))
+    ids = ctx.upload_frames([f for pr in pairs for f in pr])
+    md = np.array([40.0 / 0.6, 35.0, 50.0, 35.0], np.float32)
+    idx, dist = ctx.stereo_match(ids[0::2], ids[1::2], md, stride=1500)
+    nmatch = 0
+    for k, (l, r) in enumerate(pairs):
+        wi, wd, _ = orc.stereo_match(l, r, 480, float(md[k]))
+        assert np.array_equal(idx[k, :l.n], wi), k
+        assert np.array_equal(dist[k, :l.n], wd), k
+        nmatch += int((wd < 75).sum())
+    assert nmatch > 800
+    ctx.free_frames(ids)
