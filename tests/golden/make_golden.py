@@ -41,7 +41,43 @@ PQ_KEYS = ["desc", "proj_x", "proj_y", "proj_xr", "level", "view_cos", "flags"]
 WQ_KEYS = ["desc", "u", "v", "radius", "min_level", "max_level", "ur", "angle", "flags"]
 
 
+def make_next_rows():
+    """a12 (claim-free best-1, with and without the chi-square gate) and the SURVEY 8(f) rank-4 rows."""
+    d = {}
+    f, q = synth.window_instance(31, 2, n=300, n_queries=700, stereo=True, th=8.0)
+    rng = np.random.default_rng(31)
+    q.ur = np.where(rng.random(q.n) < 0.8, q.u - rng.uniform(0, 40, q.n), -1.0).astype(np.float32)
+    d.update(pack_frame("wf", f)); d.update(pack_q("wq", q, WQ_KEYS))
+    for chi2, dth in ((0, 100), (1, 50)):
+        best, _ = orc.search_window_free(f, q, dth, bool(chi2))
+        d[f"free{chi2}_best"] = best
+    sizes = [0, 1, 2, 3, 7, 20, 64, 65, 100]
+    off, rows = [0], []
+    for n in sizes:
+        lm = synth.random_descriptors(rng, 1)
+        rows.append(np.concatenate([synth.observe(rng, lm, 0.08) for _ in range(n)]) if n else np.zeros((0, 32), np.uint8))
+        off.append(off[-1] + n)
+    d["dd_off"] = np.array(off, np.int32); d["dd_desc"] = np.concatenate(rows)
+    d["dd_best"] = np.array([orc.distinctive_descriptor(r) for r in rows], np.int32)
+    n = 400
+    lm = synth.random_descriptors(rng, n)
+    xl = rng.uniform(16, 624, n).astype(np.float32); yl = rng.uniform(16, 464, n).astype(np.float32)
+    left = synth.make_frame(rng, lm, np.arange(n), x=xl, y=yl, with_fv=False)
+    perm = rng.permutation(n)
+    right = synth.make_frame(rng, lm, perm, x=(xl - rng.uniform(-2, 50, n).astype(np.float32))[perm],
+                             y=(yl + rng.normal(0, 1.0, n).astype(np.float32))[perm],
+                             octave=np.clip(left.octave.astype(np.int32) + rng.integers(-2, 3, n), 0, 7).astype(left.octave.dtype)[perm],
+                             with_fv=False)
+    d.update(pack_frame("sl", left)); d.update(pack_frame("sr", right))
+    si, sd, _ = orc.stereo_match(left, right, 480, 45.0)
+    d.update(stereo_idx=si, stereo_dist=sd, stereo_max_d=np.float32(45.0))
+    np.savez_compressed(os.path.join(OUT, "next_rows.npz"), **d)
+
+
 def main():
+    if "--next-only" in sys.argv:
+        make_next_rows()
+        return
     kfs = synth.keyframe_pool(seed=11, n_kf=2, n=300, window=450, mp_valid_frac=0.9, stereo_frac=0.3, bad_frac=0.05)
     a, b = kfs
     d = {}
@@ -86,6 +122,7 @@ def main():
     c, m, p, _ = orc.search_init(f1, f2, prev, 100, 0.9, True)
     d.update(init_count=c, init_match=m, init_prev=p)
     np.savez_compressed(os.path.join(OUT, "init.npz"), **d)
+    make_next_rows()
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)))

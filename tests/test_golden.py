@@ -32,6 +32,9 @@ class OracleSide:
     def proj(self, f, q, th): c, o, _ = self.orc.search_proj_points(f, q, th, 0.8); return c, o
     def win(self, mode, f, q, dth, ori): c, o, _ = self.orc.search_window(mode, f, q, dth, ori); return c, o
     def init(self, a, b, prev): c, m, p, _ = self.orc.search_init(a, b, prev, 100, 0.9, True); return c, m, p
+    def free(self, f, q, dth, chi2): return self.orc.search_window_free(f, q, dth, chi2)[0]
+    def distinct(self, off, desc): return np.array([self.orc.distinctive_descriptor(desc[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
+    def stereo(self, l, r, md): i, d, _ = self.orc.stereo_match(l, r, 480, md); return i, d
 
 
 class GpuSide:
@@ -68,6 +71,17 @@ class GpuSide:
         ids = self._up(a, b); r = self.ctx.search_init(ids[0], ids[1], prev, 100, 0.9, True); self.ctx.free_frames(ids)
         return r
 
+    def free(self, f, q, dth, chi2):
+        ids = self._up(f); qid = self.ctx.upload_win_queries([q])
+        b = self.ctx.search_window_free(ids, qid, dth, chi2, stride_q=q.n); self.ctx.free_frames(ids); self.ctx.free_queries(qid)
+        return b[0]
+
+    def distinct(self, off, desc): return self.ctx.distinctive_descriptors(off, desc)
+
+    def stereo(self, l, r, md):
+        ids = self._up(l, r); i, d = self.ctx.stereo_match([ids[0]], [ids[1]], [md], stride=l.n); self.ctx.free_frames(ids)
+        return i[0], d[0]
+
 
 def check_all(side):
     z = load("pair_bf_bow.npz")
@@ -99,6 +113,17 @@ def check_all(side):
     a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
     c, m, p = side.init(a, b, z["prev"])
     assert c == z["init_count"] and np.array_equal(m, z["init_match"]) and np.array_equal(p, z["init_prev"])
+
+
+    z = load("next_rows.npz")
+    f, q = mg.unpack_frame(z, "wf"), unpack_q(z, "wq", WinQueries, mg.WQ_KEYS)
+    for chi2, dth in ((0, 100), (1, 50)):
+        assert np.array_equal(side.free(f, q, dth, bool(chi2)), z[f"free{chi2}_best"])
+    assert (z["free0_best"] >= 0).sum() > 100 and (z["free1_best"] >= 0).sum() > 20
+    assert np.array_equal(side.distinct(z["dd_off"], z["dd_desc"]), z["dd_best"])
+    l, r = mg.unpack_frame(z, "sl"), mg.unpack_frame(z, "sr")
+    i, d = side.stereo(l, r, float(z["stereo_max_d"]))
+    assert np.array_equal(i, z["stereo_idx"]) and np.array_equal(d, z["stereo_dist"]) and (z["stereo_dist"] < 75).sum() > 100
 
 
 def test_oracle_reproduces_golden(orc):
