@@ -17,6 +17,10 @@ def counters(sub, kern="bf2nn"):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 fetch, nf = counters("fetch"); write, _ = counters("write"); sq, _ = counters("sq")
+try:
+    sq2, _ = counters("sq2"); sq.update(sq2)
+except Exception:
+    pass
 bf = [r for r in rows if "bf2nn" in r["Name"]][0]
 P, N = 4096, 2000
 alg_bytes = P * (2 * N * 32 + N * 4 + 4)      # both descriptor sets once per pair + match row + count
