@@ -179,7 +179,7 @@ constexpr int GRID_LDS_MAX_N = 8192;   // keypoint lists up to this size are ord
 
 __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restrict__ table,
                                                          const int32_t *__restrict__ ids) {
-    __shared__ uint32_t cnt[ORBM_GRID_CELLS];
+    __shared__ __align__(16) uint32_t cnt[ORBM_GRID_CELLS];
     __shared__ uint32_t off[ORBM_GRID_CELLS + 1];
     __shared__ uint32_t part[256];
     __shared__ uint16_t lidx[GRID_LDS_MAX_N];
@@ -254,6 +254,60 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
         const uint32_t k = in_lds ? (uint32_t)lidx[i] : f.cell_idx[i];
         if (in_lds) f.cell_idx[i] = k;
         f.cell_rec[i] = make_float4(f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16)));
+    }
+    // skip lists over the cell-ordered stream, one per octave pair {p-1, p}: suffix "first match at or after j".
+    // Each thread owns a run of consecutive positions; the carry from the runs to its right is a suffix-min.
+    if (f.cell_nxt && in_lds) {
+        uint16_t *firstm = reinterpret_cast<uint16_t *>(cnt);       // [256][8], cnt is free now
+        uint8_t *loct = reinterpret_cast<uint8_t *>(off);           // octave per stream position; off is free now (total is in a register)
+        __syncthreads();
+        for (uint32_t i = tid; i < total; i += 256) loct[i] = f.octave[lidx[i]];
+        __syncthreads();
+        const int per = ((int)total + 256) / 256;                    // positions 0..total-1 (+ the sentinel row `total`)
+        const int j0 = tid * per, j1 = min((int)total, j0 + per);
+        uint32_t fm[8];
+#pragma unroll
+        for (int p2 = 0; p2 < 8; p2++) fm[p2] = 0xFFFFu;
+        for (int j = j1 - 1; j >= j0; j--) {
+            const int o = loct[j];
+#pragma unroll
+            for (int p2 = 0; p2 < 8; p2++) if (o == p2 || o == p2 - 1) fm[p2] = (uint32_t)j;
+        }
+        // exclusive suffix-min of fm over the 256 threads (positions grow with tid, so the min is the nearest match)
+        uint32_t carry[8];
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int p2 = 0; p2 < 8; p2++) {
+            uint32_t v = fm[p2];                                    // inclusive suffix-min inside the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_down(v, d, 64);
+                if (lane + d < 64) v = min(v, o);
+            }
+            if (lane == 0) firstm[wv * 8 + p2] = (uint16_t)v;       // the wave's own first match
+            const uint32_t nextv = __shfl_down(v, 1, 64);           // exclusive: what the lanes to the right found
+            carry[p2] = lane < 63 ? nextv : 0xFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p2 = 0; p2 < 8; p2++) {
+            for (int w = wv + 1; w < 4; w++) carry[p2] = min(carry[p2], (uint32_t)firstm[w * 8 + p2]);
+            if (carry[p2] == 0xFFFFu) carry[p2] = total;
+        }
+        uint4 *nxt4 = reinterpret_cast<uint4 *>(f.cell_nxt);
+        if (j1 == (int)total) {
+            // whoever owns the end of the stream also writes the sentinel row (several threads may: same values)
+            const uint32_t tt = total | (total << 16);
+            nxt4[total] = make_uint4(tt, tt, tt, tt);
+        }
+        for (int j = j1 - 1; j >= j0; j--) {
+            const int o = loct[j];
+#pragma unroll
+            for (int p2 = 0; p2 < 8; p2++)
+                if (o == p2 || o == p2 - 1) carry[p2] = (uint32_t)j;
+            nxt4[j] = make_uint4(carry[0] | (carry[1] << 16), carry[2] | (carry[3] << 16), carry[4] | (carry[5] << 16),
+                                 carry[6] | (carry[7] << 16));
+        }
     }
 }
 
@@ -386,7 +440,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
     if (n_frames < 0 || (n_frames > 0 && (!views || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "frames_upload: null argument");
     if (n_frames == 0) return ORBM_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    struct Offs { size_t desc, x, y, angle, angle_raw, uright, octave, flags, cell_off, cell_idx, cell_rec, fv_node, fv_off, fv_idx; };
+    struct Offs { size_t desc, x, y, angle, angle_raw, uright, octave, flags, cell_off, cell_idx, cell_rec, cell_nxt, fv_node, fv_off, fv_idx; bool has_nxt; };
     std::vector<Offs> offs(n_frames);
     Packer pk;
     for (int k = 0; k < n_frames; k++) {
@@ -423,6 +477,8 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         o.cell_off = pk.add(nullptr, (ORBM_GRID_CELLS + 1) * 4);
         o.cell_idx = pk.add(nullptr, (n ? n : 1) * 4);
         o.cell_rec = pk.add(nullptr, (n ? n : 1) * 16);
+        o.has_nxt = v.n_levels <= 8 && v.n <= GRID_LDS_MAX_N;
+        o.cell_nxt = o.has_nxt ? pk.add(nullptr, (n + 1) * 16) : 0;
         o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4);
         o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4);
         o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4);
@@ -450,6 +506,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         f.mp_flags = (uint8_t *)(b + o.flags);
         f.cell_off = (uint32_t *)(b + o.cell_off); f.cell_idx = (uint32_t *)(b + o.cell_idx);
         f.cell_rec = (float4 *)(b + o.cell_rec);
+        f.cell_nxt = o.has_nxt ? (uint16_t *)(b + o.cell_nxt) : nullptr;
         f.fv_node = (const uint32_t *)(b + o.fv_node); f.fv_off = (const uint32_t *)(b + o.fv_off);
         f.fv_idx = (const uint32_t *)(b + o.fv_idx);
         f.min_x = v.min_x; f.min_y = v.min_y; f.max_x = v.max_x; f.max_y = v.max_y;

@@ -21,6 +21,10 @@ struct FrameDev {
     uint8_t *mp_flags;
     uint32_t *cell_off, *cell_idx;
     float4 *cell_rec;   // cell-ordered copy {x, y, uright, idx | octave << 16}: the window walk streams it
+    // cell_nxt[j * 8 + p], j in [0, T] (T = cell_off[3072] keypoints are in the grid): first position j' >= j of the
+    // cell-ordered stream whose octave is p - 1 or p (T if none): a walk that only accepts octaves {p-1, p} hops over the other records.  Null when n_levels > 8 or
+    // n > 8192.
+    uint16_t *cell_nxt;
     const uint32_t *fv_node, *fv_off, *fv_idx;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     float sf[ORBM_MAX_LEVELS];

@@ -185,13 +185,13 @@ __device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
 // then a second, wave-uniform loop computes the Hamming distances.  Each candidate that passes the static gates is
 // stored as k | oct << 16 | dist << 20 in reference visit order, in rows of 64 lanes (row i of a wave = candidate i
 // of its 64 queries; only rows some lane needs are written).
-constexpr int COLLECT_THREADS = 512;
+constexpr int COLLECT_THREADS = 1024;
 constexpr int COST_CLASSES = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
                                                                   uint32_t *cand, uint32_t *cand_hi, uint8_t *ncand_out,
-                                                                  uint64_t *postable_out, int cap) {
+                                                                  uint64_t *postable_out, int cap, int stage_nxt) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
     const int tid = threadIdx.x;
@@ -199,11 +199,20 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const int n = F.n;
     uint32_t *l_cell = lds;                                                      // 3076
     float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);                      // 4n
-    uint32_t *l_cc = lds + 3076 + 4 * (size_t)n;                                 // WIN_CACHE x COLLECT_THREADS
+    // skip lists (orbm_internal.h, cell_nxt): staged when the frame has them and the launch left room
+    const bool have_nxt = stage_nxt && F.cell_nxt != nullptr;
+    uint16_t *l_nxt = reinterpret_cast<uint16_t *>(lds + 3076 + 4 * (size_t)n);  // (n + 1) x 8
+    uint16_t *l_cc = l_nxt + (stage_nxt ? 8 * ((size_t)n + 1) : 0);              // WIN_CACHE x COLLECT_THREADS stream positions
     int *l_bucket = (int *)(l_cc + WIN_CACHE * COLLECT_THREADS);                 // cost classes
     uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + COST_CLASSES);    // 2 x COLLECT_THREADS
     for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
     for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
+    if (have_nxt) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(F.cell_nxt);
+        uint4 *l = reinterpret_cast<uint4 *>(l_nxt);
+        const int rows = (int)F.cell_off[ORBM_GRID_CELLS] + 1;
+        for (int i = tid; i < rows; i += COLLECT_THREADS) l[i] = g[i];
+    }
     __syncthreads();
     const QSrc S = query_source<MODE>(P, inst);
     const bool stereo_gate = has_stereo_gate<MODE>(S);
@@ -231,9 +240,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, t.r), inv_h)));
                 const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, t.r), inv_h)));
                 if (x1 >= x0 && y1 >= y0) {
-                    int cnt = x1 - x0 + 1;                     // loop iterations of the walk: columns + records
+                    int recs = 0;                              // loop iterations of the walk: columns + records visited
                     for (int ix = x0; ix <= x1; ix++)
-                        cnt += (int)(l_cell[ix * ORBM_GRID_ROWS + y1 + 1] - l_cell[ix * ORBM_GRID_ROWS + y0]);
+                        recs += (int)(l_cell[ix * ORBM_GRID_ROWS + y1 + 1] - l_cell[ix * ORBM_GRID_ROWS + y0]);
+                    const bool hop = have_nxt && (MODE == MODE_PROJ || MODE == MODE_SIM3 || MODE == MODE_INIT ||
+                                                  (t.maxL >= 0 && t.maxL <= 7 && t.maxL - t.minL <= 1));
+                    const int cnt = x1 - x0 + 1 + (hop ? recs / 3 : recs);
                     c = cnt < 62 ? 1 + (cnt >> 1) : min(COST_CLASSES - 1, 32 + ((cnt - 62) >> 4));
                 }
             }
@@ -291,21 +303,28 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             int ix = x0 - 1;
             uint32_t j = 0, e = 0;
             bool more = true;
+            // octaves {hi-1, hi} cover [lo, hi] when hi - lo <= 1: hop along that pair's skip list (the gates below
+            // stay, the list only leaves out records that cannot pass the level gate)
+            const bool hop = have_nxt && hi <= 7 && hi - lo <= 1;
+            const uint16_t *nx = l_nxt + (hop ? hi : 0);
             while (more) {
                 if (j >= e) {                                  // next column: one contiguous run of records
                     if (++ix > x1) more = false;
                     else {
                         j = l_cell[ix * ORBM_GRID_ROWS + y0];
                         e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
+                        if (hop) j = nx[j * 8];
                     }
                 } else {
-                    const float4 rc = l_rec[j++];
+                    const uint32_t jcur = j;
+                    const float4 rc = l_rec[j];
+                    j = hop ? (uint32_t)nx[(j + 1) * 8] : j + 1;
                     const uint32_t w = __float_as_uint(rc.w);
                     const int oct = (int)(w >> 16);
                     int pass = (int)(oct >= lo) & (int)(oct <= hi) & (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
                     if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
                     if (pass) {
-                        if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = w;
+                        if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = (uint16_t)jcur;
                         else if (ncand < cap) row_hi[(ncand - WIN_CACHE) * 64] = w;
                         ncand++;
                     }
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             for (int off = 32; off > 0; off >>= 1) wn = max(wn, __shfl_xor(wn, off, 64));
             wn = __builtin_amdgcn_readfirstlane(wn);
             for (int i = 0; i < min(wn, WIN_CACHE); i++)
-                if (i < ncand) row[i * 64] = finish(l_cc[i * COLLECT_THREADS + tid]);
+                if (i < ncand) row[i * 64] = finish(__float_as_uint(l_rec[l_cc[i * COLLECT_THREADS + tid]].w));
             for (int i = WIN_CACHE; i < wn; i++)
                 if (i < ncand) row_hi[(i - WIN_CACHE) * 64] = finish(row_hi[(i - WIN_CACHE) * 64]);
         }
@@ -767,6 +786,12 @@ int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int 
     return ORBM_OK;
 }
 
+// dynamic LDS of collect_kernel: grid, records, optional skip lists, parking (u16), cost classes, lane assignment (u16)
+static size_t collect_lds_bytes(int max_n, bool with_nxt) {
+    return (3076 + 4 * (size_t)max_n) * 4 + (with_nxt ? 16 * ((size_t)max_n + 1) : 0) + (size_t)WIN_CACHE * COLLECT_THREADS * 2 +
+           COST_CLASSES * 4 + 2 * COLLECT_THREADS * 2 + 64;
+}
+
 // tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
 // 2 = single kernel reading the frame from global memory
 int g_win_variant = 0;
@@ -775,7 +800,7 @@ template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
     // frames too large for collect_kernel's LDS staging use the single-kernel form
     const bool single = g_win_variant != 0 ||
-                        (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + COST_CLASSES) * 4 > 160 * 1024;
+                        collect_lds_bytes(max_n, false) > 160 * 1024;
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
             return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr, WIN_CACHE);
@@ -799,12 +824,13 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
         constexpr int WAVES = COLLECT_THREADS / 64;
         int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
-        const size_t lds = (3076 + 4 * (size_t)max_n + (size_t)(WIN_CACHE + 1) * COLLECT_THREADS + COST_CLASSES) * 4;
+        const int stage_nxt = collect_lds_bytes(max_n, true) <= 160 * 1024;
+        const size_t lds = collect_lds_bytes(max_n, stage_nxt != 0);
         if (lds > 48 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap);
+                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap, stage_nxt);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
         return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable, cap, cand_hi);
