@@ -18,6 +18,7 @@ namespace {
 
 constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
+constexpr int BOWQ_STAGE = 128;   // candidate rows a wave keeps in LDS for one group of queries
 
 __device__ __forceinline__ void load_row(const uint32_t *desc, int idx, uint32_t (&r)[8]) {
     const uint4 *p = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)idx;
@@ -265,6 +266,286 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
     if (tid == 0) counts[p] = nmatches;
 }
 
+// ---- second form of the same searches: QUERIES on lanes --------------------------------------------------------------
+// A vocabulary node holds ~20 features of each frame, so "64 lanes over one node's candidates" leaves two thirds of
+// the lanes idle and pays a cross-lane reduction per query.  Here a wave packs the queries of several of its nodes
+// into its 64 lanes (one query per lane) and every lane scans its own node's candidates serially: no reductions, the
+// strict-'<' first-wins order is the loop order.  Claims only couple queries of the same node, which sit on consecutive
+// lanes in query order: after the scan (which ignores claims) the lanes of a node are finalised one position at a
+// time; a lane whose best or second-best candidate has been claimed meanwhile rescans with the claimed ones left out,
+// which reproduces the sequential state exactly (claims only ever remove candidates).
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+                                                   const int32_t *__restrict__ fb, float ratio, int check_ori,
+                                                   int only_stereo, const float *__restrict__ f12all,
+                                                   const float *__restrict__ epiall, int stride,
+                                                   int32_t *__restrict__ match_all, int32_t *__restrict__ counts,
+                                                   int splits, int *__restrict__ pair_acc) {
+    __shared__ uint32_t claimed[MAX_N / 32];  // bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
+    __shared__ uint4 s_rows[4][2 * BOWQ_STAGE];   // per wave: the candidate rows of the nodes it is working on
+    __shared__ uint32_t s_meta[4][BOWQ_STAGE];    // keypoint index | mp_flags << 16 of each staged candidate
+    __shared__ int hist[ORBM_HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int nmatches;
+    const int p = SPLIT ? (int)blockIdx.x / splits : (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int part = SPLIT ? (int)blockIdx.x - p * splits : 0;
+    const int nparts = SPLIT ? splits : 1;
+    const FrameDev &A = table[fa[p]];
+    const FrameDev &B = table[fb[p]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nOut = MODE == 0 ? B.n : A.n;
+    int32_t *match = match_all + (size_t)p * stride;
+    if (!SPLIT) for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    if (MODE != 2)
+        for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
+    if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) nmatches = 0;
+    __syncthreads();
+    uint4 *w_rows = s_rows[wave];
+    uint32_t *w_meta = s_meta[wave];
+
+    const float *angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
+    float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float ex = 0.f, ey = 0.f;
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) F12[i] = f12all[(size_t)p * 9 + i];
+        ex = epiall[2 * p]; ey = epiall[2 * p + 1];
+    }
+    const uint32_t thr = (uint32_t)(MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW);           // :304 / :792 / :993
+    auto wave_max = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+
+    int my_matches = 0;
+    const int first = part * 4 + wave, nstride = 4 * nparts;
+    for (int kb = 0; first + kb * nstride < A.n_nodes; kb += 64) {
+        // 64 of this wave's nodes, one per lane: the common-node lookup (lower_bound walk of :248-352) runs in parallel
+        const int ia = first + (kb + lane) * nstride;
+        uint32_t nA = 0, nB = 0, offA = 0, offB = 0;
+        if (ia < A.n_nodes) {
+            const int ib = find_node(B.fv_node, B.n_nodes, A.fv_node[ia]);
+            if (ib >= 0) {
+                offA = A.fv_off[ia]; nA = A.fv_off[ia + 1] - offA;
+                offB = B.fv_off[ib]; nB = B.fv_off[ib + 1] - offB;
+                if (nB == 0) nA = 0;
+            }
+        }
+        int node = 0;                 // next node (a lane of this batch) with queries left
+        uint32_t node_done = 0;       // its queries already handled (nodes with more than 64 queries span groups)
+        for (;;) {
+            // ---- pack the next queries, node by node, into the 64 lanes
+            int fill = 0, my_node = -1;
+            uint32_t my_q = 0, my_take = 1, my_cbase = 0, csum = 0;
+            int my_s = 0;
+            while (node < 64 && fill < 64) {
+                const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)nA, node) - node_done;
+                if (rem == 0) { node++; node_done = 0; continue; }
+                const uint32_t take = min(rem, (uint32_t)(64 - fill));
+                if (lane >= fill && lane < fill + (int)take) {
+                    my_node = node; my_s = lane - fill; my_q = node_done + (uint32_t)my_s; my_take = take; my_cbase = csum;
+                }
+                csum += (uint32_t)__builtin_amdgcn_readlane((int)nB, node);
+                fill += (int)take;
+                if (take == rem) { node++; node_done = 0; } else { node_done += take; break; }
+            }
+            if (fill == 0) break;
+            const int src = max(my_node, 0);
+            const uint32_t mOffA = (uint32_t)__shfl((int)offA, src, 64), mOffB = (uint32_t)__shfl((int)offB, src, 64);
+            const uint32_t nb_src = (uint32_t)__shfl((int)nB, src, 64);   // all lanes take part: a shuffle cannot read a lane that sits it out
+            const uint32_t mNB = my_node >= 0 ? nb_src : 0u;
+            // ---- this lane's query
+            bool qvalid = my_node >= 0;
+            int idxA = 0;
+            uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            float x1 = 0.f, y1 = 0.f;
+            bool st1 = false;
+            if (qvalid) {
+                idxA = (int)A.fv_idx[mOffA + my_q];
+                const uint32_t fA = A.mp_flags[idxA];
+                if (MODE == 2) {
+                    st1 = A.uright[idxA] >= 0;
+                    if ((fA & ORBM_MP_PRESENT) || (only_stereo && !st1)) qvalid = false;   // :932, :939-941
+                } else {
+                    if (!(fA & ORBM_MP_PRESENT) || (fA & ORBM_MP_BAD)) qvalid = false;      // :263-267 / :746-749
+                }
+                if (qvalid) {
+                    load_row(A.desc, idxA, q);
+                    if (MODE == 2) { x1 = A.x[idxA]; y1 = A.y[idxA]; }
+                }
+            }
+            // ---- stage the candidate rows of the group's nodes in LDS: the lanes of a node share the work; every row is
+            // then read from HBM/L2 once per group instead of once per lane (groups with more rows than fit read global)
+            const bool staged = csum <= (uint32_t)BOWQ_STAGE;
+            if (staged) {
+                if (my_node >= 0)
+                    for (uint32_t t = (uint32_t)my_s; t < mNB; t += my_take) {
+                        const int idxB = (int)B.fv_idx[mOffB + t];
+                        const uint4 *g = reinterpret_cast<const uint4 *>(B.desc) + 2 * (size_t)idxB;
+                        w_rows[2 * (my_cbase + t)] = g[0];
+                        w_rows[2 * (my_cbase + t) + 1] = g[1];
+                        w_meta[my_cbase + t] = (uint32_t)idxB | ((uint32_t)B.mp_flags[idxB] << 16);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            auto staged_candidate = [&](uint32_t t, int &idxB, uint32_t (&cd)[8], uint32_t &fl) {
+                const uint4 lo = w_rows[2 * (my_cbase + t)], hi = w_rows[2 * (my_cbase + t) + 1];
+                const uint32_t m = w_meta[my_cbase + t];
+                cd[0] = lo.x; cd[1] = lo.y; cd[2] = lo.z; cd[3] = lo.w; cd[4] = hi.x; cd[5] = hi.y; cd[6] = hi.z; cd[7] = hi.w;
+                idxB = (int)(m & 0xFFFFu); fl = m >> 16;
+            };
+            auto candidate_index = [&](uint32_t t) {
+                return staged ? (int)(w_meta[my_cbase + t] & 0xFFFFu) : (int)B.fv_idx[mOffB + t];
+            };
+            // one candidate of this lane's node, already fetched: static gates + distance.  False when the reference skips it.
+            auto evaluate = [&](int idxB, const uint32_t (&cd)[8], uint32_t fl, bool skip_claimed, uint32_t &d) {
+                if (MODE == 1 && (!(fl & ORBM_MP_PRESENT) || (fl & ORBM_MP_BAD))) return false;    // :766-770
+                if (MODE != 2 && skip_claimed && ((claimed[idxB >> 5] >> (idxB & 31)) & 1u)) return false;   // :282 / :766
+                d = hamming256(q, cd);
+                if (MODE == 2) {
+                    if (d > ORBM_TH_LOW) return false;                                            // :993 (first half)
+                    const bool cst2 = B.uright[idxB] >= 0;
+                    if ((fl & ORBM_MP_PRESENT) || (only_stereo && !cst2)) return false;             // :970, :979-981
+                    const float cx2 = B.x[idxB], cy2 = B.y[idxB];
+                    const int coct2 = B.octave[idxB];
+                    if (!st1 && !cst2) {
+                        const float dex = __fsub_rn(ex, cx2), dey = __fsub_rn(ey, cy2);
+                        if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, B.sf[coct2])) return false;  // :1007
+                    }
+                    if (!check_dist_epipolar_line(x1, y1, cx2, cy2, B.sigma2[coct2], F12)) return false;  // :1014
+                }
+                return true;
+            };
+            auto update = [&](uint32_t d, uint32_t t, uint32_t &best, uint32_t &second) {
+                if (MODE == 2) {
+                    // "dist > bestDist -> skip" makes an equal distance REPLACE: lowest dist, LAST position wins
+                    best = min(best, (d << 16) | (0xFFFFu - t));
+                } else {
+                    const uint32_t key = (d << 16) | t;
+                    second = umed3(best, second, key);
+                    best = min(best, key);
+                }
+            };
+            // rescan of one lane (rare): candidates claimed meanwhile are left out
+            auto scan = [&](bool skip_claimed, uint32_t &best, uint32_t &second) {
+                best = INITKEY; second = INITKEY;
+                for (uint32_t t = 0; t < mNB; t++) {
+                    int idxB; uint32_t cd[8], fl;
+                    if (staged) staged_candidate(t, idxB, cd, fl);
+                    else { idxB = (int)B.fv_idx[mOffB + t]; load_row(B.desc, idxB, cd); fl = B.mp_flags[idxB]; }
+                    uint32_t d = 0;
+                    if (evaluate(idxB, cd, fl, skip_claimed, d)) update(d, t, best, second);
+                }
+            };
+            // ---- scan: every lane against its own node's candidates, claims ignored.  The loads run ahead of the
+            // arithmetic: index two candidates ahead, descriptor and flags one ahead (lanes of a node read the same rows).
+            uint32_t best = INITKEY, second = INITKEY;
+            if (staged) {
+                const int tmax = wave_max(qvalid ? (int)mNB : 0);
+                for (int t = 0; t < tmax; t++) {
+                    if (qvalid && (uint32_t)t < mNB) {
+                        int idxB; uint32_t cd[8], fl, d = 0;
+                        staged_candidate((uint32_t)t, idxB, cd, fl);
+                        if (evaluate(idxB, cd, fl, false, d)) update(d, (uint32_t)t, best, second);
+                    }
+                }
+            } else {
+                const int tmax = wave_max(qvalid ? (int)mNB : 0);
+                const uint32_t last = mNB ? mNB - 1 : 0;
+                const bool on = qvalid && mNB > 0;
+                int idx_cur = on ? (int)B.fv_idx[mOffB] : 0;
+                int idx_nxt = on ? (int)B.fv_idx[mOffB + min(1u, last)] : 0;
+                uint32_t row_nxt[8];
+                load_row(B.desc, idx_cur, row_nxt);
+                uint32_t fl_nxt = B.mp_flags[idx_cur];
+                for (int t = 0; t < tmax; t++) {
+                    uint32_t cd[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) cd[i] = row_nxt[i];
+                    const uint32_t fl = fl_nxt;
+                    const int idxB = idx_cur;
+                    // issue the loads of the next candidates before touching this one
+                    idx_cur = idx_nxt;
+                    load_row(B.desc, idx_cur, row_nxt);
+                    fl_nxt = B.mp_flags[idx_cur];
+                    idx_nxt = on ? (int)B.fv_idx[mOffB + min((uint32_t)t + 2u, last)] : 0;
+                    if (on && (uint32_t)t < mNB) {
+                        uint32_t d = 0;
+                        if (evaluate(idxB, cd, fl, false, d)) update(d, (uint32_t)t, best, second);
+                    }
+                }
+            }
+            if (MODE == 2) {
+                if (qvalid && best != INITKEY) {                                                  // bestIdx2 >= 0  (:1021)
+                    const int idx2 = candidate_index(0xFFFFu - (best & 0xFFFFu));
+                    match[idxA] = idx2;
+                    if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], B.angle[idx2])], 1);
+                    my_matches++;
+                }
+                continue;
+            }
+            // ---- finalise in query order inside each node.  A best distance above the threshold can only get worse.
+            if ((best >> 16) > thr) qvalid = false;
+            const int smax = wave_max(qvalid ? my_s + 1 : 0);
+            for (int s2 = 0; s2 < smax; s2++) {
+                if (qvalid && my_s == s2) {
+                    int ib1 = candidate_index(best & 0xFFFFu);
+                    bool stale = (claimed[ib1 >> 5] >> (ib1 & 31)) & 1u;
+                    if (!stale && second != INITKEY) {
+                        const int ib2 = candidate_index(second & 0xFFFFu);
+                        stale = (claimed[ib2 >> 5] >> (ib2 & 31)) & 1u;
+                    }
+                    if (stale) {
+                        scan(true, best, second);
+                        if (best != INITKEY) ib1 = candidate_index(best & 0xFFFFu);
+                    }
+                    const int bd = (int)(best >> 16), sd = (int)(second >> 16);
+                    const bool pass = MODE == 0 ? (bd <= ORBM_TH_LOW) : (bd < ORBM_TH_LOW);       // :304 / :792
+                    if (pass && (float)bd < __fmul_rn(ratio, (float)sd)) {                         // :308 / :796
+                        atomicOr(&claimed[ib1 >> 5], 1u << (ib1 & 31));                            // :312 / :799
+                        if (MODE == 0) match[ib1] = idxA; else match[idxA] = ib1;
+                        if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[ib1])], 1);
+                        my_matches++;
+                    }
+                }
+                // claims must be visible to the later positions of the same node (same wave)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (my_matches) atomicAdd(&nmatches, my_matches);
+    __syncthreads();
+    if (SPLIT) {
+        if (tid < ORBM_HISTO_LENGTH && hist[tid]) atomicAdd(&pair_acc[p * 32 + tid], hist[tid]);
+        if (tid == 0 && nmatches) atomicAdd(&pair_acc[p * 32 + 30], nmatches);
+        return;
+    }
+    if (check_ori) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        int removed = 0;
+        for (int i = tid; i < nOut; i += 256) {
+            const int m = match[i];
+            if (m < 0) continue;
+            const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
+            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+            if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }        // :368-381 etc.
+        }
+        if (removed) atomicSub(&nmatches, removed);
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = nmatches;
+}
+
 // rotation-consistency filter + count of a pair whose nodes were matched by several workgroups (:355-383 / :827-849 / :1062-1082)
 template <int MODE>
 __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
@@ -305,6 +586,10 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
     if (tid == 0) counts[p] = pair_acc[p * 32 + 30] - removed_all;
 }
 
+// tuning / test knob: 0 = auto (large batches: queries on lanes, bowq_kernel; small batches, where several workgroups
+// share a pair and a wave gets one or two nodes: candidates on lanes, bow_kernel), 1 = bow_kernel always, 2 = bowq_kernel always
+int g_bow_variant = 0;
+
 int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, const int32_t *frame_b, float ratio,
                int check_ori, int only_stereo, const float *f12, const float *epipole, int32_t stride,
                int32_t *match, int32_t *counts, int io_on_device, const char *who) {
@@ -342,7 +627,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     if (splits == 1) {
         dim3 grid(n_pairs);
 #define LAUNCH(M)                                                                                              \
-    hipLaunchKernelGGL((bow_kernel<M, false>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,        \
+    hipLaunchKernelGGL((g_bow_variant == 1 ? bow_kernel<M, false> : bowq_kernel<M, false>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                        (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
                        stride, (int32_t *)dm, (int32_t *)dc, 1, (int *)nullptr)
         if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
@@ -356,7 +641,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         dim3 grid(n_pairs * splits), fgrid(n_pairs);
 #define LAUNCH(M)                                                                                              \
     do {                                                                                                       \
-        hipLaunchKernelGGL((bow_kernel<M, true>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,     \
+        hipLaunchKernelGGL((g_bow_variant != 2 ? bow_kernel<M, true> : bowq_kernel<M, true>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
                            stride, (int32_t *)dm, (int32_t *)dc, splits, acc);                                  \
         hipLaunchKernelGGL((bow_finish_kernel<M>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,   \
@@ -370,6 +655,9 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
 }
 
 }  // namespace
+
+// tuning / test knob (not part of the public ABI): see g_bow_variant
+extern "C" void orbm__bow_variant(int v) { g_bow_variant = v; }
 
 extern "C" int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
                                      const int32_t *frame_b, float ratio, int check_ori, int32_t stride,

@@ -72,6 +72,46 @@ def test_triang_large_batch(ctx, orc):
     ctx.free_frames(ids)
 
 
+@pytest.mark.parametrize("form", [1, 2])
+def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
+    """The BoW searches exist in two forms (candidates on lanes / queries on lanes; the library picks by batch size):
+    both give the reference's result on every kind of input, for small and large batches."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    try:
+        L.orbm__bow_variant(form)
+        kfs = synth.keyframe_pool(seed=synth.SEED0 + 24, n_kf=4, n=1200) + contended_pool(31, 3, 700, 150) + \
+            contended_pool(41, 2, 300, 10, n_nodes=2)                     # nodes far wider than a wavefront
+        ids = ctx.upload_frames(kfs)
+        pa, pb = np.meshgrid(np.arange(len(kfs)), np.arange(len(kfs)))
+        pa, pb = pa.ravel(), pb.ravel()
+        for reps in (1, 7):                                               # 81 pairs (split path) and 567 pairs
+            qa, qb = np.tile(pa, reps), np.tile(pb, reps)
+            for variant in (0, 1):
+                counts, match = ctx.search_bow(variant, ids[qa], ids[qb], 0.8, True, stride=1200)
+                for k in range(len(pa)):
+                    i, j = pa[k], pb[k]
+                    wc, wm, _ = orc.search_bow(variant, kfs[i], kfs[j], 0.8, True)
+                    for r in range(reps):
+                        kk = r * len(pa) + k
+                        assert counts[kk] == wc and np.array_equal(match[kk, :len(wm)], wm), (form, reps, variant, i, j)
+        ctx.free_frames(ids)
+        cases = [synth.triang_pair(150 + s2, n=900) for s2 in range(2)]
+        ids = ctx.upload_frames([f for c in cases for f in c[:2]])
+        for reps in (1, 300):
+            fa, fb = np.tile(ids[0::2], reps), np.tile(ids[1::2], reps)
+            f12 = np.tile(np.stack([c[2] for c in cases]), (reps, 1, 1)); ep = np.tile(np.stack([c[3] for c in cases]), (reps, 1))
+            for only_stereo in (False, True):
+                counts, match = ctx.search_triang(fa, fb, f12, ep, only_stereo, True, stride=900)
+                for k, c in enumerate(cases):
+                    wc, wm, _ = orc.search_triang(c[0], c[1], c[2], c[3], only_stereo, True)
+                    for r in range(reps):
+                        assert counts[r * 2 + k] == wc and np.array_equal(match[r * 2 + k], wm), (form, reps, only_stereo, k)
+        ctx.free_frames(ids)
+    finally:
+        L.orbm__bow_variant(0)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_bow_parity_contended_claims(ctx, orc, variant):
     kfs = contended_pool(11 + variant, 5, 700, 150) + contended_pool(21, 2, 300, 10, n_nodes=2)  # nodes > 64 wide
