@@ -16,11 +16,14 @@
 //   evaluate : every unresolved query walks its window in reference order against the current slot state
 //              and posts its chunk-local index with atomicMin on every slot it could still claim
 //              (distance <= acceptance threshold);
-//   decide   : a query is FINAL iff no lower-index unresolved query posted on its best (and, where a ratio test
-//              reads it, second-best) free slot; final queries apply their result to the slot state.
-// A query can only ever claim a slot it posted on and slots only ever become blocked, so the best / second-best
-// pair of a final query is the one the sequential loop would have found; the lowest unresolved query is always
-// final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
+//              and, where a ratio test reads it, on its second-best free slot whatever its distance;
+//   contested: a query is contested if a lower-index unresolved query posted on its best or second-best free slot;
+//              a contested query posts on ALL its free candidates (any of them may end up in its top two);
+//   decide   : an uncontested query is FINAL if it takes nothing, or if no lower-index unresolved query has its best
+//              slot posted; final queries apply their result to the slot state.
+// Slots only ever become blocked and a post means "a lower query's outcome may depend on this slot staying free", so
+// the best / second-best pair of a final query is the one the sequential loop would have found; the lowest
+// unresolved query is always final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
 #include <limits.h>
 #include <string.h>
 #include <algorithm>
@@ -546,16 +549,59 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                     else walk_window<false>(acc, x, y, r, minL, maxL, body);
                 }
             }
+            // a query that can still be accepted also names its second-best free slot where a ratio test reads it: lower
+            // queries' interest in a slot must be visible to whoever wants to take it (claimable slots are posted above)
+            constexpr bool USES_SECOND = MODE == MODE_PROJ || MODE == MODE_INIT;
+            const bool live = unresolved && bestIdx >= 0 && bestDist <= thr;
+            if (live && USES_SECOND && bestIdx2 >= 0) atomicMin(&post[bestIdx2], (uint32_t)tid);
             __syncthreads();
+            // ---- contested? ---------------------------------------------------------------------------
+            // The outcome is a function of the best and (where a ratio test reads it) the second-best free candidate, and
+            // slots only ever become blocked.  If a lower-index unresolved query may still take one of those two, this
+            // query is not settled, and ANY of its free candidates may end up in its top two: it posts on all of them so
+            // that no later query takes one of them first.
+            bool contested = false;
+            if (live) {
+                contested = post[bestIdx] < (uint32_t)tid;
+                if (USES_SECOND && bestIdx2 >= 0 && post[bestIdx2] < (uint32_t)tid) contested = true;
+            }
+            if (__syncthreads_or(contested ? 1 : 0)) {
+                if (contested) {
+                    if (cached) {
+                        for (int i = 0; i < wave_ncand; i++) {
+                            const uint32_t v = cand_at(i);
+                            if (i < ncand) {
+                                const int k = (int)(v & 0xFFFFu);
+                                if (!is_blocked(state[k], (int)(v >> 20))) atomicMin(&post[k], (uint32_t)tid);
+                            }
+                        }
+                    } else {
+                        auto body = [&](int k, int oct, float ur) {
+                            if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
+                            if (MODE == MODE_INIT) {
+                                const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                                const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                                if (is_blocked(state[k], (int)hamming256(qd, cd))) return;
+                            } else if (is_blocked(state[k], 0)) return;
+                            atomicMin(&post[k], (uint32_t)tid);
+                        };
+                        if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, body);
+                        else walk_window<false>(acc, x, y, r, minL, maxL, body);
+                    }
+                }
+                __syncthreads();
+            }
             // ---- decide -----------------------------------------------------------------------------
             if (unresolved) {
-                // The outcome is a function of the best and (where a ratio test reads it) the second-best free candidate.
-                // Slots only ever become blocked, so it can change only if a lower-index unresolved query may still take
-                // one of those two; a best distance above the threshold can only get worse, so that is final at once.
-                bool is_final = true;
-                if (bestIdx >= 0 && bestDist <= thr) {
-                    if (post[bestIdx] < (uint32_t)tid) is_final = false;
-                    if ((MODE == MODE_PROJ || MODE == MODE_INIT) && bestIdx2 >= 0 && post[bestIdx2] < (uint32_t)tid) is_final = false;
+                // not live: a best distance above the threshold can only get worse, final at once.  Otherwise final when
+                // uncontested and, if it takes its best slot, no lower-index unresolved query has that slot posted.
+                bool is_final = !live;
+                if (live && !contested) {
+                    bool accept0;
+                    if (MODE == MODE_PROJ) accept0 = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2));
+                    else if (MODE == MODE_INIT) accept0 = (float)bestDist < __fmul_rn((float)bestDist2, P.ratio);
+                    else accept0 = true;
+                    is_final = !accept0 || post[bestIdx] >= (uint32_t)tid;
                 }
                 if (is_final) {
                     unresolved = false;

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from orbslam2_amd import synth
-from orbslam2_amd.views import MP_PRESENT, MP_OBS, MP_BAD, FrameData, ProjQueries
+from orbslam2_amd.views import MP_PRESENT, MP_OBS, MP_BAD, Q_VALID, Q_OBS, FrameData, ProjQueries
 
 pytestmark = pytest.mark.gpu
 
@@ -397,3 +397,54 @@ def test_stereo_match_parity(ctx, orc):
         nmatch += int((wd < 75).sum())
     assert nmatch > 800
     ctx.free_frames(ids)
+
+
+def _bits(idx):
+    d = np.zeros(32, np.uint8)
+    for i in idx:
+        d[i >> 3] |= 1 << (i & 7)
+    return d
+
+
+def test_proj_second_best_above_threshold_is_not_claimed_early(ctx, orc):
+    """Adversarial order dependence (SearchByProjection(F, MapPoints), ratio test on the second-best):
+    keypoints a, b, c; queries i < j < k.  i takes a but could also take b (so j waits for i); k's best is c, which
+    nobody lower could take (j's distance to c is 105 > TH_HIGH).  j's outcome still depends on c: with c free its
+    second-best is 105 and the ratio test rejects it (90 > 0.8 * 105), with c taken it would be accepted.  A later
+    query must therefore not take c before j is settled."""
+    Sb, Sc, rest = list(range(0, 70)), list(range(70, 141)), list(range(141, 256))
+    a, b, c = _bits([]), _bits(Sb), _bits(Sc)
+    e = _bits(Sc[:45] + rest[60:100])               # k's second-best (46); out of reach of i and j (115, 119)
+    qi = _bits(Sb[:30])                              # d(a) = 30, d(b) = 40, d(c) = 101
+    qj = _bits(Sb[:40] + Sc[:33] + rest[:27])        # d(b) = 90, d(c) = 105, d(a) = 100
+    qk = _bits(Sc[:51])                              # d(c) = 20, d(a) = 51, d(b) = 121
+    assert [orc.hamming256(qi, v) for v in (a, b, c)] == [30, 40, 101]
+    assert [orc.hamming256(qj, v) for v in (a, b, c)] == [100, 90, 105]
+    assert orc.hamming256(qk, c) == 20 and orc.hamming256(qk, e) == 46 and orc.hamming256(qk, a) == 51
+    assert orc.hamming256(qi, e) == 115 and orc.hamming256(qj, e) == 119
+    # padding queries in front so that the three land in one chunk at arbitrary lanes, and far-away keypoints
+    rng = np.random.default_rng(5)
+    n_far = 40
+    f = FrameData(desc=np.concatenate([np.stack([a, b, c, e]), synth.random_descriptors(rng, n_far)]),
+                  x=np.concatenate([[300.0, 303.0, 306.0, 301.0], rng.uniform(20, 100, n_far)]).astype(np.float32),
+                  y=np.concatenate([[200.0, 202.0, 204.0, 205.0], rng.uniform(20, 100, n_far)]).astype(np.float32),
+                  angle=np.zeros(4 + n_far, np.float32), octave=np.full(4 + n_far, 2, np.int32))
+    for pad in (0, 5, 70, 1030):
+        nq = pad + 3
+        desc = np.concatenate([synth.random_descriptors(rng, pad), np.stack([qi, qj, qk])]) if pad else np.stack([qi, qj, qk])
+        px = np.concatenate([rng.uniform(400, 600, pad), [302.0, 303.0, 304.0]]).astype(np.float32)
+        py = np.concatenate([rng.uniform(300, 450, pad), [201.0, 202.0, 203.0]]).astype(np.float32)
+        q = ProjQueries(desc=desc, proj_x=px, proj_y=py, proj_xr=np.full(nq, -1.0, np.float32), level=np.full(nq, 2, np.int32),
+                        view_cos=np.full(nq, 0.95, np.float32), flags=np.full(nq, Q_VALID | Q_OBS, np.uint8))
+        wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8)
+        assert wo[0] == pad and wo[1] == -1 and wo[2] == pad + 2 and wo[3] == -1 and wc == 2      # a <- i, b free, c <- k
+        fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
+        for variant in (0, 1, 2):
+            from orbslam2_amd import _lib
+            _lib.load().orbm__window_variant(variant)
+            try:
+                counts, owner = ctx.search_proj_points(fid, qid, 3.0, 0.8, stride=f.n)
+            finally:
+                _lib.load().orbm__window_variant(0)
+            assert counts[0] == wc and np.array_equal(owner[0], wo), (pad, variant, owner[0][:4])
+        ctx.free_frames(fid); ctx.free_queries(qid)
