@@ -448,3 +448,67 @@ def test_proj_second_best_above_threshold_is_not_claimed_early(ctx, orc):
                 _lib.load().orbm__window_variant(0)
             assert counts[0] == wc and np.array_equal(owner[0], wo), (pad, variant, owner[0][:4])
         ctx.free_frames(fid); ctx.free_queries(qid)
+
+
+def _dense_frame(rng, n, lm_desc):
+    lm = rng.integers(0, len(lm_desc), n)
+    return synth.make_frame(rng, lm_desc, lm, x=rng.uniform(200, 300, n).astype(np.float32), y=rng.uniform(200, 300, n).astype(np.float32),
+                            octave=rng.integers(2, 4, n).astype(np.int32), p_flip=0.02, with_fv=False,
+                            mp_flags=np.where(rng.random(n) < 0.1, MP_PRESENT | MP_OBS, 0).astype(np.uint8)), lm
+
+
+def test_claim_rounds_fuzz_near_thresholds(ctx, orc):
+    """Many small, crowded instances whose query-to-keypoint distances straddle the acceptance thresholds and whose
+    windows overlap almost completely: the in-order claim rules decide nearly every match (a6 with its ratio test on
+    the second-best, a11 best-only, a5 with stealing)."""
+    rng = np.random.default_rng(2024)
+    frames, pqs, wqs, inits = [], [], [], []
+    for trial in range(160):
+        n = int(rng.integers(20, 90)); nq = int(rng.integers(50, 400))
+        lm_desc = synth.random_descriptors(rng, int(rng.integers(5, 40)))
+        f, lm = _dense_frame(rng, n, lm_desc)
+        frames.append(f)
+        src = rng.integers(0, n, nq)
+        p_flip = rng.choice([0.05, 0.2, 0.3, 0.36, 0.4, 0.44], nq)
+        desc = np.stack([synth.observe(rng, lm_desc[lm[s]][None, :], p)[0] for s, p in zip(src, p_flip)])
+        px = (f.x[src] + rng.normal(0, 6, nq)).astype(np.float32); py = (f.y[src] + rng.normal(0, 6, nq)).astype(np.float32)
+        pqs.append(ProjQueries(desc=desc, proj_x=px, proj_y=py, proj_xr=np.full(nq, -1.0, np.float32),
+                               level=np.clip(f.octave[src] + rng.integers(0, 2, nq), 0, 7).astype(np.int32),
+                               view_cos=rng.uniform(0.9, 1.0, nq).astype(np.float32),
+                               flags=np.where(rng.random(nq) < 0.95, Q_VALID, 0).astype(np.uint8) | np.where(rng.random(nq) < 0.7, Q_OBS, 0).astype(np.uint8)))
+        from orbslam2_amd.views import WinQueries
+        wqs.append(WinQueries(desc=desc, u=px, v=py, radius=rng.uniform(15, 60, nq).astype(np.float32),
+                              min_level=(f.octave[src] - 1).astype(np.int32), max_level=(f.octave[src] + 1).astype(np.int32),
+                              ur=None, angle=rng.uniform(0, 360, nq).astype(np.float32),
+                              flags=np.where(rng.random(nq) < 0.95, Q_VALID | Q_OBS, 0).astype(np.uint8)))
+    fid = ctx.upload_frames(frames)
+    qid = ctx.upload_proj_queries(pqs)
+    for th in (3.0, 6.0):
+        counts, owner = ctx.search_proj_points(fid, qid, th, 0.8, stride=90)
+        for k, (f, q) in enumerate(zip(frames, pqs)):
+            wc, wo, _ = orc.search_proj_points(f, q, th, 0.8)
+            assert counts[k] == wc and np.array_equal(owner[k, :f.n], wo), ("proj", th, k)
+    ctx.free_queries(qid)
+    wid = ctx.upload_win_queries(wqs)
+    for mode, dth in ((0, 100), (1, 90), (2, 50), (2, 110)):
+        counts, owner = ctx.search_window(mode, fid, wid, dth, mode < 2, stride=90)
+        for k, (f, q) in enumerate(zip(frames, wqs)):
+            wc, wo, _ = orc.search_window(mode, f, q, dth, mode < 2)
+            assert counts[k] == wc and np.array_equal(owner[k, :f.n], wo), ("win", mode, dth, k)
+    ctx.free_queries(wid); ctx.free_frames(fid)
+    # a5: level-0 keypoints only, window covering everything, distances around TH_LOW, ratio near 1
+    for trial in range(40):
+        n1 = int(rng.integers(30, 200)); n2 = int(rng.integers(20, 120))
+        lm_desc = synth.random_descriptors(rng, int(rng.integers(5, 30)))
+        l1 = rng.integers(0, len(lm_desc), n1); l2 = rng.integers(0, len(lm_desc), n2)
+        mk = lambda lm, n: synth.make_frame(rng, lm_desc, lm, x=rng.uniform(250, 330, n).astype(np.float32),
+                                            y=rng.uniform(200, 280, n).astype(np.float32), octave=np.where(rng.random(n) < 0.8, 0, 1).astype(np.int32),
+                                            p_flip=float(rng.choice([0.05, 0.1, 0.12])), with_fv=False)
+        f1, f2 = mk(l1, n1), mk(l2, n2)
+        prev = np.stack([f1.x, f1.y], 1).astype(np.float32)
+        ids = ctx.upload_frames([f1, f2])
+        for ratio in (0.9, 0.99):
+            cnt, m12, prev_out = ctx.search_init(ids[0], ids[1], prev, 100, ratio, True)
+            wc, wm, wprev, _ = orc.search_init(f1, f2, prev, 100, ratio, True)
+            assert cnt == wc and np.array_equal(m12, wm) and np.array_equal(prev_out, wprev), ("init", trial, ratio)
+        ctx.free_frames(ids)
