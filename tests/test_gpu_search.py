@@ -512,3 +512,40 @@ def test_claim_rounds_fuzz_near_thresholds(ctx, orc):
             wc, wm, wprev, _ = orc.search_init(f1, f2, prev, 100, ratio, True)
             assert cnt == wc and np.array_equal(m12, wm) and np.array_equal(prev_out, wprev), ("init", trial, ratio)
         ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_bow_fuzz_near_thresholds(ctx, orc, form):
+    """Both BoW kernel forms on crowded nodes whose distances straddle TH_LOW and the ratio test."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4242 + form)
+    kfs = []
+    for trial in range(24):
+        n = int(rng.integers(30, 400))
+        lm_desc = synth.random_descriptors(rng, int(rng.integers(4, 40)))
+        lm = rng.integers(0, len(lm_desc), n)
+        flags = np.where(rng.random(n) < 0.9, MP_PRESENT | MP_OBS, 0).astype(np.uint8)
+        flags[(rng.random(n) < 0.05) & (flags != 0)] |= MP_BAD
+        kfs.append(synth.make_frame(rng, lm_desc, lm, mp_flags=flags, p_flip=float(rng.choice([0.05, 0.1, 0.12])),
+                                    n_nodes=int(rng.choice([1, 3, 10])), octave=rng.integers(0, 8, n).astype(np.int32)))
+    ids = ctx.upload_frames(kfs)
+    pa = rng.integers(0, len(kfs), 600); pb = rng.integers(0, len(kfs), 600)
+    try:
+        L.orbm__bow_variant(form)
+        for variant in (0, 1):
+            for ratio in (0.75, 0.95):
+                counts, match = ctx.search_bow(variant, ids[pa], ids[pb], ratio, True, stride=400)
+                want = {}
+                for k, (i, j) in enumerate(zip(pa, pb)):
+                    if (i, j) not in want:
+                        want[(i, j)] = orc.search_bow(variant, kfs[i], kfs[j], ratio, True)
+                    wc, wm, _ = want[(i, j)]
+                    assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (form, variant, ratio, k)
+                counts, match = ctx.search_bow(variant, ids[pa[:40]], ids[pb[:40]], ratio, True, stride=400)   # split path
+                for k in range(40):
+                    wc, wm, _ = want[(pa[k], pb[k])]
+                    assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (form, variant, ratio, k, "split")
+    finally:
+        L.orbm__bow_variant(0)
+    ctx.free_frames(ids)
