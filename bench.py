@@ -111,6 +111,18 @@ def secondary(ctx, torch, dev, kfs, ids):
         ctx.search_bow_dev(1, 8192, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
         e1.record(); torch.cuda.synchronize()
     out["search_bow_kfkf_pairs_per_s"] = round(8192 / (e0.elapsed_time(e1) * 1e-3), 1)
+    # config 4 as stated: ONE frame against 64 candidate keyframes (relocalisation / loop closure), SearchByBoW(KF, F)
+    cand = ids[rng.choice(len(ids), 64, replace=False)].astype(np.int32)
+    tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(64, ids[0], np.int32), device=dev)
+    best = 1e30
+    for rep in range(5):
+        e0, e1 = ev(), ev(); e0.record()
+        ctx.search_bow_dev(0, 64, tca.data_ptr(), tcb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
+        e1.record(); torch.cuda.synchronize()
+        if rep:
+            best = min(best, e0.elapsed_time(e1))
+    out["search_bow_64_candidates_ms"] = round(best, 4)
+    out["search_bow_64_candidates_pairs_per_s"] = round(64 / (best * 1e-3), 1)
     # config 3: SearchByProjection (th = 3), 50k map points into a 2000-keypoint frame.  Batch of instances with
     # distinct query sets (permutations of one set, so the queries really stream from HBM), then one instance alone.
     from orbslam2_amd.views import ProjQueries
