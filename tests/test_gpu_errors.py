@@ -1,0 +1,55 @@
+"""Error behaviour of the C ABI (through the ctypes mirror): bad arguments are refused with a message, nothing is
+launched, and the context stays usable."""
+import numpy as np
+import pytest
+
+from orbslam2_amd import synth
+from orbslam2_amd.views import FrameData
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments_are_refused_and_context_survives(ctx, orc):
+    from orbslam2_amd.matcher import OrbmError
+    kfs = synth.keyframe_pool(seed=5, n_kf=2, n=200)
+    ids = ctx.upload_frames(kfs)
+    f, q = synth.proj_instance(seed=6, n=200, n_queries=300)
+    fw, qw = synth.window_instance(7, 1, n=200, n_queries=100)
+    pid = ctx.upload_proj_queries([q]); wid = ctx.upload_win_queries([qw])
+    bad_calls = [
+        lambda: ctx.bf2nn([ids[0]], [9999], 0.75, 50, stride=200),                       # unknown frame id
+        lambda: ctx.bf2nn([ids[0]], [-1], 0.75, 50, stride=200),
+        lambda: ctx.bf2nn([ids[0]], [ids[1]], 0.75, 50, stride=10),                      # stride below the row count
+        lambda: ctx.search_bow(2, [ids[0]], [ids[1]], 0.75, True, stride=200),           # variant out of range
+        lambda: ctx.search_bow(0, [ids[0]], [ids[1]], 0.75, True, stride=5),
+        lambda: ctx.search_proj_points([ids[0]], wid, 3.0, 0.8, stride=200),             # window query set given to the a6 entry
+        lambda: ctx.search_window(1, [ids[0]], pid, 64, True, stride=200),               # and the other way round
+        lambda: ctx.search_window(7, [ids[0]], wid, 64, True, stride=200),               # mode out of range
+        lambda: ctx.search_window_free([ids[0]], wid, 50, True, stride_q=100),           # chi-square gate without ur
+        lambda: ctx.search_window_free([ids[0]], wid, 50, False, stride_q=10),           # stride below the query count
+        lambda: ctx.stereo_match([ids[0]], [ids[1]], [40.0], stride=10),
+    ]
+    for k, call in enumerate(bad_calls):
+        with pytest.raises(OrbmError) as e:
+            call()
+        assert str(e.value), k
+    # malformed frames are refused at upload
+    rng = np.random.default_rng(0)
+    lm = synth.random_descriptors(rng, 10)
+    g = synth.make_frame(rng, lm, np.arange(10))
+    g.octave = g.octave.copy(); g.octave[3] = 9                                          # outside [0, n_levels)
+    with pytest.raises(OrbmError):
+        ctx.upload_frames([g])
+    g = synth.make_frame(rng, lm, np.arange(10))
+    g.fv_idx = g.fv_idx.copy(); g.fv_idx[0] = 10                                         # FeatureVector index out of range
+    with pytest.raises(OrbmError):
+        ctx.upload_frames([g])
+    # a freed id is dead
+    ctx.free_frames([ids[1]])
+    with pytest.raises(OrbmError):
+        ctx.bf2nn([ids[0]], [ids[1]], 0.75, 50, stride=200)
+    # ... and the context still works
+    c, m, bd, sd = ctx.bf2nn([ids[0]], [ids[0]], 0.75, 50, stride=200)
+    wc, wm, wb, ws, _ = orc.bf2nn(kfs[0], kfs[0], 0.75, 50)
+    assert c[0] == wc and np.array_equal(m[0], wm)
+    ctx.free_frames([ids[0]]); ctx.free_queries(pid); ctx.free_queries(wid)
