@@ -21,6 +21,14 @@ def orc():
 
 @pytest.fixture(scope="session")
 def ctx():
+    # tests that hand torch device tensors to the library need torch's HIP runtime initialised first: once
+    # liborbmatch_hip.so has brought up the system runtime, torch's own initialisation no longer finds the GPU
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from orbslam2_amd.matcher import Context
     c = Context(0)
     yield c

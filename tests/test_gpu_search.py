@@ -549,3 +549,36 @@ def test_bow_fuzz_near_thresholds(ctx, orc, form):
     finally:
         L.orbm__bow_variant(0)
     ctx.free_frames(ids)
+
+
+def test_all_pairs_end_to_end_on_one_gpu(ctx, orc):
+    """BASELINE config 5 in small: every keyframe pair of a resident store through allpairs.all_pairs (device index lists,
+    device outputs, fixed-stride records), one rank; every record against the oracle."""
+    import torch
+    from orbslam2_amd import allpairs
+    n_kf, n = 20, 500
+    kfs = synth.keyframe_pool(seed=synth.SEED0 + 5, n_kf=n_kf, n=n, window=int(n / 0.6))
+    ids = ctx.upload_frames(kfs)
+    dev = torch.device("cuda:0")
+    tid = torch.tensor(ids, device=dev, dtype=torch.int32)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    batch = 64
+
+    def match_fn(ta, tb):
+        fa = tid[ta.long()].contiguous(); fb = tid[tb.long()].contiguous()
+        match = torch.empty((batch, n), dtype=torch.int32, device=dev); counts = torch.empty(batch, dtype=torch.int32, device=dev)
+        ctx.search_bow_dev(1, batch, fa.data_ptr(), fb.data_ptr(), 0.75, True, n, match.data_ptr(), counts.data_ptr())
+        return counts, match
+
+    try:
+        res = allpairs.all_pairs(torch, None, n_kf, stride=n, batch=batch, match_fn=match_fn, device=dev, tile=8)
+    finally:
+        ctx.use_own_stream()
+    assert len(res) == n_kf * (n_kf - 1) // 2
+    tot = 0
+    for (a, b), (cnt, row) in res.items():
+        wc, wm, _ = orc.search_bow(1, kfs[a], kfs[b], 0.75, True)
+        assert cnt == wc and np.array_equal(row, wm), (a, b)
+        tot += wc
+    assert tot > 2000
+    ctx.free_frames(ids)
