@@ -111,6 +111,27 @@ def secondary(ctx, torch, dev, kfs, ids):
         ctx.search_bow_dev(1, 8192, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
         e1.record(); torch.cuda.synchronize()
     out["search_bow_kfkf_pairs_per_s"] = round(8192 / (e0.elapsed_time(e1) * 1e-3), 1)
+    # config 2 again with the opt-in early-abandon kernel (ORBMATCH_BF2NN_EARLY_ABANDON=1): identical matches, but the
+    # last 64 bits of a comparison are skipped when the first 192 already reach the tracking bound, so this is NOT the
+    # headline (which evaluates every distance in full); reported as reference-equivalent comparisons per second
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    fa2, fb2 = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
+    tfa2 = torch.tensor(fa2, device=dev); tfb2 = torch.tensor(fb2, device=dev)
+    m2 = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
+    try:
+        L.orbm__bf2nn_variant(8)
+        best = 1e30
+        for rep in range(4):
+            e0, e1 = ev(), ev(); e0.record()
+            ctx.bf2nn_dev(PAIRS_PER_STEP, tfa2.data_ptr(), tfb2.data_ptr(), RATIO, TH, N_FEAT, m2.data_ptr(), None, None, c2.data_ptr())
+            e1.record(); torch.cuda.synchronize()
+            if rep:
+                best = min(best, e0.elapsed_time(e1))
+    finally:
+        L.orbm__bf2nn_variant(0)
+    out["bf2nn_early_abandon_pairs_per_s"] = round(PAIRS_PER_STEP / (best * 1e-3), 1)
+    out["bf2nn_early_abandon_equivalent_Gcmps"] = round(PAIRS_PER_STEP * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
     # config 4 as stated: ONE frame against 64 candidate keyframes (relocalisation / loop closure), SearchByBoW(KF, F)
     cand = ids[rng.choice(len(ids), 64, replace=False)].astype(np.int32)
     tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(64, ids[0], np.int32), device=dev)

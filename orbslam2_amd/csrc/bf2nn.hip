@@ -18,6 +18,7 @@
 //     only fires for candidates that can matter.  All nA x nB distances are still evaluated.
 // Candidate rows are staged global -> LDS in coalesced 16-byte loads, TILE rows at a time; all lanes read
 // the same LDS row (broadcast ds_read_b128 x2) and reuse it for their R queries.
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "orbm_internal.h"
@@ -43,6 +44,30 @@ __device__ __forceinline__ uint32_t hamming256_biased(const uint32_t (&a)[8], co
     return d;
 }
 
+// the same chain in two pieces (early-abandon variant): words [0, 6) seeded with the bias, then words [6, 8) on top
+__device__ __forceinline__ uint32_t hamming192_biased(const uint32_t (&a)[8], const uint32_t (&b)[6], uint32_t bias) {
+    uint32_t d;
+    {
+        const uint32_t x = a[0] ^ b[0];
+        asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(bias));
+    }
+#pragma unroll
+    for (int i = 1; i < 6; i++) {
+        const uint32_t x = a[i] ^ b[i];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    return d;
+}
+__device__ __forceinline__ uint32_t hamming64_more(const uint32_t (&a)[8], uint32_t b6, uint32_t b7, uint32_t d) {
+    const uint32_t x6 = a[6] ^ b6, x7 = a[7] ^ b7;
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x6));
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x7));
+    return d;
+}
+
+// DIAG 0: product kernel.  1 / 2: timing diagnostics.  3: EARLY ABANDON (opt-in, reported separately by bench.py): a
+// distance only grows, so when the first 192 bits of every comparison of a group already reach the tracking bound the
+// last 64 bits cannot change anything and are skipped (same results; not every distance is evaluated in full).
 template <int R, int U, int DIAG>
 __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__ table,
                                                     const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
@@ -85,6 +110,30 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
         for (; j + U <= rows; j += U) {
             uint32_t acc[U][R];
             uint32_t m = 0xFFFFFFFFu;
+            if (DIAG == 3) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint4 c0 = tile[2 * (j + u)];
+                    const uint2 c1 = *reinterpret_cast<const uint2 *>(&tile[2 * (j + u) + 1]);
+                    const uint32_t c[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        acc[u][r] = hamming192_biased(q[r], c, bias[r]);
+                        m &= acc[u][r];
+                    }
+                }
+                if (!__any((int)m >= 0)) continue;       // every partial distance already at the bound: group done
+                m = 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint2 c2 = *(reinterpret_cast<const uint2 *>(&tile[2 * (j + u) + 1]) + 1);
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        acc[u][r] = hamming64_more(q[r], c2.x, c2.y, acc[u][r]);
+                        m &= acc[u][r];
+                    }
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint4 c0 = tile[2 * (j + u)], c1 = tile[2 * (j + u) + 1];
@@ -198,7 +247,9 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         for (int t = std::max(th + 1, 1); t <= 256; t++)
             if ((float)th < ratio * (float)t) { track_below = t; break; }
     }
-    const int variant = g_bf_variant;
+    // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
+    static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
+    const int variant = (g_bf_variant == 0 && env_early_abandon) ? 8 : g_bf_variant;
     const int R = (variant == 0 || variant == 3 || variant >= 7 || variant < 0) ? 2 : 4;
     const int bpp = (max_na + 256 * R - 1) / (256 * R);
     const long long grid = (long long)n_pairs * bpp;
@@ -214,6 +265,7 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         case 4: BF_LAUNCH(4, 2, 1); break;   // diagnostic: no exact updates (results wrong)
         case 5: BF_LAUNCH(4, 2, 2); break;   // diagnostic: exact update on every group
         case 6: BF_LAUNCH(4, 4, 0); break;
+        case 8: BF_LAUNCH(BF_R, BF_U, 3); break;   // early abandon (opt-in)
         default: BF_LAUNCH(BF_R, BF_U, 0); break;
     }
 #undef BF_LAUNCH

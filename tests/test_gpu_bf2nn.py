@@ -95,6 +95,42 @@ def test_bf2nn_batch_many_pairs(ctx, orc):
     ctx.free_frames(ids)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8])
+def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
+    """Tile-shape variants, the track-everything variant and the opt-in early-abandon variant (8: the last 64 bits of
+    a comparison are skipped once the first 192 already reach the tracking bound) all return the reference's matches,
+    with and without the raw distances, across thresholds and ratios."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    kfs = synth.keyframe_pool(seed=78, n_kf=5, n=700, window=1000) + contended_frames(79)
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.meshgrid(np.arange(len(kfs)), np.arange(len(kfs)))
+    pa, pb = pa.ravel(), pb.ravel()
+    try:
+        L.orbm__bf2nn_variant(variant)
+        for ratio, th in ((0.75, 50), (0.6, 50), (0.95, 100), (1.5, 30), (0.75, 0), (0.9, 256)):
+            for want_dist in (False, True):
+                counts, match, bd, sd = ctx.bf2nn(ids[pa], ids[pb], ratio, th, stride=700, want_dist=want_dist)
+                for k, (i, j) in enumerate(zip(pa, pb)):
+                    wc, wm, wbd, wsd, _ = orc.bf2nn(kfs[i], kfs[j], ratio, th)
+                    assert counts[k] == wc and np.array_equal(match[k, :kfs[i].n], wm), (variant, ratio, th, want_dist, i, j)
+                    if want_dist:
+                        assert np.array_equal(bd[k, :kfs[i].n], wbd) and np.array_equal(sd[k, :kfs[i].n], wsd)
+    finally:
+        L.orbm__bf2nn_variant(0)
+    ctx.free_frames(ids)
+
+
+def contended_frames(seed):
+    """Frames re-observing a small landmark pool with little noise: many near-ties around the thresholds."""
+    rng = np.random.default_rng(seed)
+    lm = synth.random_descriptors(rng, 40)
+    out = []
+    for p_flip, n in ((0.02, 300), (0.1, 450), (0.2, 200)):
+        out.append(synth.make_frame(rng, lm, rng.integers(0, 40, n), with_fv=False, p_flip=p_flip))
+    return out
+
+
 def test_errors_are_loud(ctx):
     from orbslam2_amd.matcher import OrbmError
     with pytest.raises(OrbmError):
