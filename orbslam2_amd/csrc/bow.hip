@@ -491,6 +491,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
             if ((best >> 16) > thr) qvalid = false;
             const int smax = wave_max(qvalid ? my_s + 1 : 0);
             for (int s2 = 0; s2 < smax; s2++) {
+                if (!__any(qvalid && my_s == s2)) continue;       // nobody left at this position (most queries have no plausible match)
                 if (qvalid && my_s == s2) {
                     int ib1 = candidate_index(best & 0xFFFFu);
                     bool stale = (claimed[ib1 >> 5] >> (ib1 & 31)) & 1u;
