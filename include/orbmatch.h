@@ -143,6 +143,39 @@ int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
 int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist,
                           int io_on_device);
 
+/* ---- DBoW2 TemplatedVocabulary::transform(features, ..., FeatureVector, levelsup), word / node part,
+ * as called by Frame::ComputeBoW (Frame.cc:526-533) and KeyFrame::ComputeBoW (KeyFrame.cc:69-78) with levelsup = 4.
+ * DBoW2 is not part of the reference tree; the tree arrives flat.  Node 0 is the root; the children of node i are
+ * child_idx[child_off[i] .. child_off[i+1]) in DBoW2's stored order (ties go to the first child), every child id is
+ * larger than its parent's and the root has children; desc = 32 bytes per node (row 0 unused); word_id = the word of a
+ * leaf, -1 for inner nodes; weight = the node weights (nullable = all positive): transform() leaves a feature whose word
+ * has weight <= 0 out of the FeatureVector ("if (w > 0)"); depth = L (levels below the root).  */
+typedef struct orbm_vocab_view {
+    int32_t n_nodes, depth;
+    const uint32_t *child_off;   /* n_nodes + 1 */
+    const uint32_t *child_idx;
+    const uint8_t *desc;         /* n_nodes x 32 */
+    const int32_t *word_id;      /* n_nodes */
+    const double *weight;        /* n_nodes or NULL */
+} orbm_vocab_view;
+int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *vocab, int32_t *vocab_id);
+int orbm_vocab_free(orbm_ctx *ctx, int32_t vocab_id);
+/* For every listed frame (host array of ids, each at most once): descends the tree with each descriptor and REPLACES the
+ * frame's device-resident FeatureVector with the one DBoW2 would build (node at level depth - levelsup, nodes ascending,
+ * feature indices ascending inside a node), so that orbm_search_bow_batch / orbm_search_triang_batch need no
+ * FeatureVector from the host.  word_id / node_id (host, n_frames x stride, nullable) receive the per-feature word id
+ * and node id (node id -1: the word's weight is not positive, the feature is in no node); rows beyond a frame's n are
+ * -1.  Limit: 8192 features per frame. */
+int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_frames, const int32_t *frames, int levelsup,
+                            int32_t stride, int32_t *word_id, int32_t *node_id);
+/* The same descent for n bare descriptors (32 bytes each; host, or device and 16-byte aligned when io_on_device):
+ * word_id[n], node_id[n] as above.  What a per-call ORBVocabulary::transform needs before a frame exists. */
+int orbm_vocab_transform(orbm_ctx *ctx, int32_t vocab_id, int n, const uint8_t *desc, int levelsup, int32_t *word_id,
+                         int32_t *node_id, int io_on_device);
+/* Copies a frame's device-resident FeatureVector to the host: fv_node[n_nodes], fv_off[n_nodes + 1], fv_idx[fv_off[n_nodes]];
+ * the arrays must hold n, n + 1 and n entries (n = the frame's feature count). */
+int orbm_frame_fv_download(orbm_ctx *ctx, int32_t frame, int32_t *n_nodes, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx);
+
 /* ---- descriptor stage of Frame::ComputeStereoMatches (Frame.cc:632-728), batched over stereo
  * frames.  frame_left / frame_right are uploaded views whose x, y, octave, desc are mvKeys / mvKeysRight and
  * mDescriptors / mDescriptorsRight (raw, not undistorted, coordinates); scale_factors as in the frame.

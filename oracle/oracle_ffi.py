@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from orbslam2_amd.views import CFrameView, CProjQueries, CWinQueries, GRID_CELLS
+from orbslam2_amd.views import CFrameView, CProjQueries, CVocabView, CWinQueries, GRID_CELLS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liborb_oracle.so")
@@ -50,6 +50,7 @@ def lib():
         L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
         L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
         L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
+        L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p]
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         _lib = L
     return _lib
@@ -182,3 +183,18 @@ def distinctive_descriptor(desc) -> int:
 
 def predict_scale(max_distance, current_dist, log_scale_factor, n_levels) -> int:
     return int(lib().orc_predict_scale(max_distance, current_dist, log_scale_factor, n_levels))
+
+
+def transform(vocab, desc, levelsup: int):
+    """-> word_id[n], node_id[n] (-1: weight not positive), (fv_node, fv_off, fv_idx)"""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(d)
+    word = np.zeros(max(n, 1), np.int32)
+    node = np.zeros(max(n, 1), np.int32)
+    fv_node = np.zeros(max(n, 1), np.uint32)
+    fv_off = np.zeros(n + 1, np.uint32)
+    fv_idx = np.zeros(max(n, 1), np.uint32)
+    v = vocab.view()
+    nn = lib().orc_transform(C.byref(v), _p(d, C.c_uint8) if n else None, n, levelsup, _p(word, C.c_int32), _p(node, C.c_int32),
+                             _p(fv_node, C.c_uint32), _p(fv_off, C.c_uint32), _p(fv_idx, C.c_uint32))
+    return word[:n], node[:n], (fv_node[:nn].copy(), fv_off[:nn + 1].copy(), fv_idx[:int(fv_off[nn])].copy())

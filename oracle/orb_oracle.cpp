@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <limits.h>
+#include <map>
 #include <vector>
 #include <algorithm>
 
@@ -681,6 +682,80 @@ int orc_distinctive_descriptor(const uint8_t *desc, int n) {
         }
     }
     return BestIdx;
+}
+
+// DBoW2 (third-party dependency of the reference, absent from its tree; parity unpinned): TemplatedVocabulary<FORB::TDescriptor,
+// FORB>::transform(features, BowVector&, FeatureVector&, levelsup), word / node part, as Frame.cc:526-533 and KeyFrame.cc:69-78
+// call it.  The tree is rebuilt from the flat view into DBoW2's own shape (a vector of nodes with child-id vectors) and the
+// FeatureVector is the std::map<NodeId, std::vector<unsigned>> that FeatureVector::addFeature fills.
+int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out,
+                  uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx) {
+    struct Node {
+        std::vector<uint32_t> children;
+        const uint8_t *descriptor;
+        double weight;
+        int32_t word_id;
+        bool isLeaf() const { return children.empty(); }
+    };
+    std::vector<Node> m_nodes(V->n_nodes);
+    for (int i = 0; i < V->n_nodes; i++) {
+        Node &nd = m_nodes[i];
+        nd.children.assign(V->child_idx + V->child_off[i], V->child_idx + V->child_off[i + 1]);
+        nd.descriptor = V->desc + 32 * (size_t)i;
+        nd.weight = V->weight ? V->weight[i] : 1.0;
+        nd.word_id = V->word_id[i];
+    }
+    const int m_L = V->depth;
+    std::map<uint32_t, std::vector<unsigned int>> fv;
+    for (int i_feature = 0; i_feature < n; i_feature++) {
+        const uint8_t *feature = desc + 32 * (size_t)i_feature;
+        // transform(feature, word_id, weight, &nid, levelsup)
+        std::vector<uint32_t> nodes;
+        const int nid_level = m_L - levelsup;
+        uint32_t nid = 0;
+        if (nid_level <= 0) nid = 0;   // root
+        uint32_t final_id = 0;         // root
+        int current_level = 0;
+        do {
+            ++current_level;
+            nodes = m_nodes[final_id].children;
+            final_id = nodes[0];
+            double best_d = orc_hamming256(feature, m_nodes[final_id].descriptor);
+            for (auto nit = nodes.begin() + 1; nit != nodes.end(); ++nit) {
+                uint32_t id = *nit;
+                double d = orc_hamming256(feature, m_nodes[id].descriptor);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (!m_nodes[final_id].isLeaf());
+        int32_t word_id = m_nodes[final_id].word_id;
+        double w = m_nodes[final_id].weight;
+        if (word_out) word_out[i_feature] = word_id;
+        if (node_out) node_out[i_feature] = w > 0 ? (int32_t)nid : -1;
+        if (w > 0) {   // not stopped
+            // FeatureVector::addFeature(nid, i_feature)
+            auto vit = fv.lower_bound(nid);
+            if (vit != fv.end() && vit->first == nid)
+                vit->second.push_back(i_feature);
+            else {
+                vit = fv.insert(vit, std::make_pair(nid, std::vector<unsigned int>()));
+                vit->second.push_back(i_feature);
+            }
+        }
+    }
+    int j = 0;
+    uint32_t pos = 0;
+    for (auto &kv : fv) {
+        fv_node[j] = kv.first;
+        fv_off[j] = pos;
+        for (unsigned int i : kv.second) fv_idx[pos++] = i;
+        j++;
+    }
+    fv_off[j] = pos;
+    return j;
 }
 
 // MapPoint.cc:569-602 (PredictScale) in flat form: host-side helper of the a11 gates.  MapPoint.cc sees

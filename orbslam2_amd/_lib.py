@@ -3,7 +3,7 @@ library is missing or fails to load, importing a matcher raises."""
 import ctypes as C
 import os
 
-from .views import CFrameView, CProjQueries, CWinQueries
+from .views import CFrameView, CProjQueries, CVocabView, CWinQueries
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbmatch_hip.so")
@@ -15,6 +15,7 @@ SYMBOLS = [
     "orbm_proj_queries_upload", "orbm_win_queries_upload", "orbm_queries_free",
     "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_stereo_match_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
     "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
+    "orbm_vocab_upload", "orbm_vocab_free", "orbm_frames_compute_bow", "orbm_vocab_transform", "orbm_frame_fv_download",
     "orbm_popcount_peak",
 ]
 
@@ -58,6 +59,11 @@ def load():
     L.orbm_search_window_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, i32, vp, vp, C.c_int]
     L.orbm_search_window_free_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, i32, vp, C.c_int]
     L.orbm_search_init.argtypes = [vp, i32, i32, vp, C.c_int, f32, C.c_int, vp]
+    L.orbm_vocab_upload.argtypes = [vp, C.POINTER(CVocabView), C.POINTER(i32)]
+    L.orbm_vocab_free.argtypes = [vp, i32]
+    L.orbm_frames_compute_bow.argtypes = [vp, i32, C.c_int, vp, C.c_int, i32, vp, vp]
+    L.orbm_vocab_transform.argtypes = [vp, i32, C.c_int, vp, C.c_int, vp, vp, C.c_int]
+    L.orbm_frame_fv_download.argtypes = [vp, i32, C.POINTER(i32), vp, vp, vp]
     L.orbm_popcount_peak.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library does not export a declared symbol

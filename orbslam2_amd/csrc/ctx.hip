@@ -1,5 +1,6 @@
 // ctx.hip -- context, device-resident frame / query-set storage, grid-cell index build (a15, a16),
 // batched DescriptorDistance (a1) and the popcount-rate micro-kernel (K0).
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -377,6 +378,7 @@ void orbm_destroy(orbm_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &a : ctx->arenas) if (a.base) (void)hipFree(a.base);
     for (auto &a : ctx->arena_pool) if (a.base) (void)hipFree(a.base);
+    for (auto &v : ctx->vocabs) if (v.arena.base) (void)hipFree(v.arena.base);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_qsets) (void)hipFree(ctx->d_qsets);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -426,9 +428,9 @@ static int grow_table(orbm_ctx *ctx, void **d_tab, size_t *cap, size_t need, siz
 struct Packer {
     std::vector<uint8_t> host;
     size_t off = 0;
-    size_t add(const void *src, size_t bytes) {   // src may be null: reserved, zero-filled
+    size_t add(const void *src, size_t bytes, size_t cap = 0) {   // src may be null: reserved, zero-filled; cap >= bytes reserves room
         size_t o = off;
-        off = align_up(off + bytes, 256);
+        off = align_up(off + std::max(bytes, cap), 256);
         host.resize(off, 0);
         if (src && bytes) memcpy(host.data() + o, src, bytes);
         return o;
@@ -479,9 +481,10 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         o.cell_rec = pk.add(nullptr, (n ? n : 1) * 16);
         o.has_nxt = v.n_levels <= 8 && v.n <= GRID_LDS_MAX_N;
         o.cell_nxt = o.has_nxt ? pk.add(nullptr, (n + 1) * 16) : 0;
-        o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4);
-        o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4);
-        o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4);
+        // room for a FeatureVector computed on the device later (orbm_frames_compute_bow): at most one node per feature
+        o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4, n * 4);
+        o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4, (n + 1) * 4);
+        o.fv_idx = pk.add(v.fv_idx, (size_t)nfv * 4, n * 4);
     }
     Arena ar;
     { int rc = orbm_arena_alloc(ctx, pk.off, &ar); if (rc) return rc; }

@@ -48,6 +48,15 @@ struct Arena {
     int live = 0;       // objects still referencing it
 };
 
+// Device-resident vocabulary tree (DBoW2 TemplatedVocabulary): node 0 is the root, children of node i are
+// child_idx[child_off[i] .. child_off[i+1]) in stored order, 32-byte descriptor per node, word id per leaf (-1 inside).
+struct VocabDev {
+    int32_t n_nodes = 0, depth = 0;
+    const uint32_t *child_off = nullptr, *child_idx = nullptr, *desc = nullptr;
+    const int32_t *word_id = nullptr;
+    Arena arena;
+};
+
 struct orbm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -67,6 +76,7 @@ struct orbm_ctx {
     QSetDev *d_qsets = nullptr;
     size_t d_qsets_cap = 0;
     std::vector<Arena> arenas;
+    std::vector<VocabDev> vocabs;      // slot free when arena.base == nullptr
     // released arenas kept for reuse: per-call uploads of the drop-in class (a frame, a query set) would otherwise
     // pay a hipMalloc + hipFree each; bounded in count and bytes
     std::vector<Arena> arena_pool;

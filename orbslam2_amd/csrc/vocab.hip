@@ -1,0 +1,273 @@
+// vocab.hip -- SURVEY 8(f) rank 3: the word / node part of DBoW2's TemplatedVocabulary::transform for ORB descriptors
+// (called by Frame::ComputeBoW, Frame.cc:526-533, and KeyFrame::ComputeBoW, KeyFrame.cc:69-78, with levelsup = 4) and
+// the FeatureVector it fills, computed and kept on the device: the searches of bow.hip then need no host-built
+// FeatureVector upload.  DBoW2 is not in the reference tree; the descent is its published algorithm:
+//   final_id = root; do { final_id = the child with the least Hamming distance (first child wins ties);
+//                         if (level == L - levelsup) nid = final_id; } while (!leaf);   word = word_id[final_id]
+// and FeatureVector::addFeature(nid, i) in feature order == CSR with ascending node ids, ascending indices per node.
+//
+// transform_kernel: one lane per feature, the children of a node are read from the resident tree (contiguous ids when
+// the tree is stored breadth-first, as DBoW2 saves it).  fv_build_kernel: one workgroup per frame, bitonic sort of
+// (node id << 32 | feature index) in LDS, run heads -> fv_node / fv_off, indices -> fv_idx, and the frame's n_nodes.
+#include <algorithm>
+#include <string.h>
+#include "orbm_internal.h"
+
+namespace {
+
+constexpr int FV_MAX_N = 8192;     // features per frame the LDS sort holds (64 KB of 8-byte keys)
+
+// one descriptor down the tree -> {word id | stopped << 31, node id at level depth - levelsup}
+__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ g, int levelsup, int32_t &word, int &nid) {
+    const uint4 lo = g[0], hi = g[1];
+    const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const int nid_level = V.depth - levelsup;
+    nid = 0;                                       // nid_level <= 0: the root
+    uint32_t final_id = 0;
+    int level = 0;
+    for (;;) {
+        const uint32_t b = V.child_off[final_id], e = V.child_off[final_id + 1];
+        if (b == e) break;                         // leaf
+        ++level;
+        uint32_t best_id = 0, best_d = 0xFFFFFFFFu;
+        for (uint32_t c = b; c < e; c++) {
+            const uint32_t id = V.child_idx[c];
+            const uint4 *cg = reinterpret_cast<const uint4 *>(V.desc) + 2 * (size_t)id;
+            const uint4 clo = cg[0], chi = cg[1];
+            const uint32_t cd[8] = {clo.x, clo.y, clo.z, clo.w, chi.x, chi.y, chi.z, chi.w};
+            const uint32_t d = hamming256(q, cd);
+            if (d < best_d) { best_d = d; best_id = id; }          // strict '<': the first child wins ties
+        }
+        final_id = best_id;
+        if (level == nid_level) nid = (int)final_id;
+    }
+    word = V.word_id[final_id];                    // bit 31: the word's weight is not positive
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ ids,
+                                                        VocabDev V, int levelsup, int blocks_per_frame, int stride,
+                                                        int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
+    const int f = blockIdx.x / blocks_per_frame;
+    const int i = (blockIdx.x - f * blocks_per_frame) * 256 + (int)threadIdx.x;
+    const FrameDev &F = table[ids[f]];
+    if (i >= F.n) return;
+    int32_t w; int nid;
+    descend(V, reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)i, levelsup, w, nid);
+    word_out[(size_t)f * stride + i] = w & 0x7FFFFFFF;
+    node_out[(size_t)f * stride + i] = w < 0 ? -1 : nid;
+}
+
+__global__ __launch_bounds__(256) void transform_flat_kernel(const uint32_t *__restrict__ desc, int n, VocabDev V, int levelsup,
+                                                             int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= n) return;
+    int32_t w; int nid;
+    descend(V, reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)i, levelsup, w, nid);
+    word_out[i] = w & 0x7FFFFFFF;
+    node_out[i] = w < 0 ? -1 : nid;
+}
+
+__global__ __launch_bounds__(256) void fv_build_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int stride,
+                                                       const int32_t *__restrict__ node_in, int32_t *__restrict__ n_nodes_out) {
+    extern __shared__ __align__(16) unsigned long long keys[];
+    __shared__ uint32_t part[256];
+    __shared__ int n_in;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    FrameDev &F = table[ids[f]];
+    const int n_feat = F.n;
+    int m = 1;
+    while (m < n_feat) m <<= 1;
+    if (tid == 0) n_in = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < m; i += 256) {
+        const int node = i < n_feat ? node_in[(size_t)f * stride + i] : -1;
+        keys[i] = node >= 0 ? ((unsigned long long)(uint32_t)node << 32) | (uint32_t)i : ~0ull;     // left out: sorts last
+        mine += node >= 0;
+    }
+    if (mine) atomicAdd(&n_in, mine);
+    __syncthreads();
+    const int n = n_in;
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    uint32_t *fv_node = const_cast<uint32_t *>(F.fv_node), *fv_off = const_cast<uint32_t *>(F.fv_off), *fv_idx = const_cast<uint32_t *>(F.fv_idx);
+    // run heads: thread t owns positions [t*per, (t+1)*per)
+    const int per = (n + 255) / 256;
+    const int p0 = tid * per, p1 = min(n, p0 + per);
+    uint32_t heads = 0;
+    for (int p = p0; p < p1; p++) heads += (p == 0 || (keys[p] >> 32) != (keys[p - 1] >> 32)) ? 1u : 0u;
+    part[tid] = heads;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int t = 0; t < tid; t++) base += part[t];
+    uint32_t total = base;
+    for (int t = tid; t < 256; t++) total += part[t];
+    for (int p = p0; p < p1; p++) {
+        const unsigned long long kp = keys[p];
+        fv_idx[p] = (uint32_t)kp;
+        if (p == 0 || (kp >> 32) != (keys[p - 1] >> 32)) { fv_node[base] = (uint32_t)(kp >> 32); fv_off[base] = (uint32_t)p; base++; }
+    }
+    if (tid == 0) { fv_off[total] = (uint32_t)n; F.n_nodes = (int32_t)total; n_nodes_out[f] = (int32_t)total; }
+}
+
+}  // namespace
+
+extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_t *vocab_id) {
+    if (!ctx) return ORBM_EINVAL;
+    if (!v || !vocab_id) return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: null argument");
+    if (v->n_nodes < 2 || !v->child_off || !v->desc || !v->word_id)
+        return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: empty tree or null array");
+    const size_t nn = (size_t)v->n_nodes;
+    const uint32_t nchild = v->child_off[nn];
+    if (v->child_off[0] != 0 || v->child_off[1] == 0 || !v->child_idx) return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: bad child_off or a root without children");
+    // every node but the root is the child of exactly one EARLIER node: the descent then always terminates
+    std::vector<uint8_t> seen(nn, 0);
+    for (size_t i = 0; i < nn; i++) {
+        if (v->child_off[i + 1] < v->child_off[i]) return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: child_off not monotone at node %zu", i);
+        for (uint32_t c = v->child_off[i]; c < v->child_off[i + 1]; c++) {
+            const uint32_t id = v->child_idx[c];
+            if (id >= nn || id <= i || seen[id]) return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: node %zu has a bad child %u", i, id);
+            seen[id] = 1;
+        }
+        if (v->child_off[i + 1] == v->child_off[i] && v->word_id[i] < 0)
+            return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: leaf %zu has no word id", i);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t o_off = 0, o_idx = (nn + 1) * 4, o_desc = ((o_idx + (size_t)nchild * 4 + 255) / 256) * 256;
+    const size_t o_word = o_desc + nn * 32, total = o_word + nn * 4;
+    VocabDev V;
+    { int rc = orbm_arena_alloc(ctx, total, &V.arena); if (rc) return rc; }
+    char *b = (char *)V.arena.base;
+    HIPCHK(ctx, hipMemcpy(b + o_off, v->child_off, (nn + 1) * 4, hipMemcpyHostToDevice));
+    if (nchild) HIPCHK(ctx, hipMemcpy(b + o_idx, v->child_idx, (size_t)nchild * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b + o_desc, v->desc, nn * 32, hipMemcpyHostToDevice));
+    std::vector<int32_t> words(v->word_id, v->word_id + nn);
+    for (size_t i = 0; i < nn; i++) {
+        const bool leaf = v->child_off[i + 1] == v->child_off[i];
+        if (leaf && v->weight && !(v->weight[i] > 0)) words[i] |= (int32_t)0x80000000;     // "if (w > 0)" of transform()
+    }
+    HIPCHK(ctx, hipMemcpy(b + o_word, words.data(), nn * 4, hipMemcpyHostToDevice));
+    V.n_nodes = v->n_nodes; V.depth = v->depth;
+    V.child_off = (const uint32_t *)(b + o_off); V.child_idx = (const uint32_t *)(b + o_idx);
+    V.desc = (const uint32_t *)(b + o_desc); V.word_id = (const int32_t *)(b + o_word);
+    int id = -1;
+    for (size_t i = 0; i < ctx->vocabs.size(); i++) if (!ctx->vocabs[i].arena.base) { id = (int)i; break; }
+    if (id < 0) { ctx->vocabs.push_back(V); id = (int)ctx->vocabs.size() - 1; } else ctx->vocabs[id] = V;
+    *vocab_id = id;
+    return ORBM_OK;
+}
+
+extern "C" int orbm_vocab_free(orbm_ctx *ctx, int32_t vocab_id) {
+    if (!ctx) return ORBM_EINVAL;
+    if (vocab_id < 0 || (size_t)vocab_id >= ctx->vocabs.size() || !ctx->vocabs[vocab_id].arena.base)
+        return orbm_fail(ctx, ORBM_EINVAL, "vocab_free: %d is not a live vocabulary", vocab_id);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    orbm_arena_release(ctx, ctx->vocabs[vocab_id].arena);
+    ctx->vocabs[vocab_id] = VocabDev();
+    return ORBM_OK;
+}
+
+extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_frames, const int32_t *frames, int levelsup,
+                                       int32_t stride, int32_t *word_id, int32_t *node_id) {
+    if (!ctx) return ORBM_EINVAL;
+    if (vocab_id < 0 || (size_t)vocab_id >= ctx->vocabs.size() || !ctx->vocabs[vocab_id].arena.base)
+        return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: %d is not a live vocabulary", vocab_id);
+    if (n_frames < 0 || (n_frames > 0 && !frames) || stride < 0) return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: null argument or negative size");
+    if (n_frames == 0) return ORBM_OK;
+    int rc = orbm_check_frames(ctx, n_frames, frames, "frames");
+    if (rc) return rc;
+    int max_n = 0;
+    for (int k = 0; k < n_frames; k++) {
+        for (int j = 0; j < k; j++) if (frames[j] == frames[k]) return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: frame %d listed twice", frames[k]);
+        max_n = std::max(max_n, ctx->h_frames[frames[k]].n);
+    }
+    if (max_n > FV_MAX_N) return orbm_fail(ctx, ORBM_ELIMIT, "frames_compute_bow: frames of more than %d features are not supported (got %d)", FV_MAX_N, max_n);
+    if ((word_id || node_id) && max_n > stride) return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: stride %d < largest frame %d", stride, max_n);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int st = std::max(std::max(stride, max_n), 1);
+    const size_t elems = (size_t)n_frames * st;
+    rc = orbm_ws_reserve(ctx, (size_t)n_frames * 8 + (word_id ? elems * 4 : 0) + (node_id ? elems * 4 : 0) + 4096);
+    if (rc) return rc;
+    rc = orbm_ws2_reserve(ctx, elems * 8 + 512);         // outputs the caller does not ask for stay on the device
+    if (rc) return rc;
+    IoStage io(ctx, 0);
+    const void *dids; void *dw, *dn, *dnn;
+    std::vector<int32_t> nn(n_frames);
+    if ((rc = io.in(frames, (size_t)n_frames * 4, &dids)) || (rc = io.out(nn.data(), (size_t)n_frames * 4, &dnn)) ||
+        (rc = io.out(word_id, elems * 4, &dw)) || (rc = io.out(node_id, elems * 4, &dn)))
+        return rc;
+    if (!dw) dw = ctx->ws2;
+    if (!dn) dn = (char *)ctx->ws2 + ((elems * 4 + 255) / 256) * 256;
+    HIPCHK(ctx, hipMemsetAsync(dw, 0xFF, elems * 4, ctx->stream));         // rows beyond a frame's n stay -1
+    HIPCHK(ctx, hipMemsetAsync(dn, 0xFF, elems * 4, ctx->stream));
+    const VocabDev &V = ctx->vocabs[vocab_id];
+    if (max_n > 0) {
+        const int bpf = (max_n + 255) / 256;
+        hipLaunchKernelGGL(transform_kernel, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
+                           (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    int m = 1;
+    while (m < max_n) m <<= 1;
+    const size_t lds = (size_t)m * 8;
+    if (lds > 48 * 1024)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fv_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fv_build_kernel, dim3(n_frames), dim3(256), lds, ctx->stream, ctx->d_frames, (const int32_t *)dids, st,
+                       (const int32_t *)dn, (int32_t *)dnn);
+    HIPCHK(ctx, hipGetLastError());
+    rc = io.finish();
+    if (rc) return rc;
+    // keep the host mirror of the frame table in step (it is re-sent when the table grows)
+    for (int k = 0; k < n_frames; k++) ctx->h_frames[frames[k]].n_nodes = nn[k];
+    return ORBM_OK;
+}
+
+extern "C" int orbm_frame_fv_download(orbm_ctx *ctx, int32_t frame, int32_t *n_nodes, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx) {
+    if (!ctx) return ORBM_EINVAL;
+    if (!n_nodes || !fv_node || !fv_off || !fv_idx) return orbm_fail(ctx, ORBM_EINVAL, "frame_fv_download: null argument");
+    int rc = orbm_check_frames(ctx, 1, &frame, "frame");
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const FrameDev &h = ctx->h_frames[frame];
+    const int nn = h.n_nodes;
+    *n_nodes = nn;
+    HIPCHK(ctx, hipMemcpy(fv_off, h.fv_off, ((size_t)nn + 1) * 4, hipMemcpyDeviceToHost));
+    if (nn > 0) {
+        HIPCHK(ctx, hipMemcpy(fv_node, h.fv_node, (size_t)nn * 4, hipMemcpyDeviceToHost));
+        if (fv_off[nn] > (uint32_t)std::max(h.n, 0)) return orbm_fail(ctx, ORBM_EINVAL, "frame_fv_download: FeatureVector of %u entries exceeds the frame's %d features", fv_off[nn], h.n);
+        if (fv_off[nn]) HIPCHK(ctx, hipMemcpy(fv_idx, h.fv_idx, (size_t)fv_off[nn] * 4, hipMemcpyDeviceToHost));
+    }
+    return ORBM_OK;
+}
+
+extern "C" int orbm_vocab_transform(orbm_ctx *ctx, int32_t vocab_id, int n, const uint8_t *desc, int levelsup, int32_t *word_id,
+                                    int32_t *node_id, int io_on_device) {
+    if (!ctx) return ORBM_EINVAL;
+    if (vocab_id < 0 || (size_t)vocab_id >= ctx->vocabs.size() || !ctx->vocabs[vocab_id].arena.base)
+        return orbm_fail(ctx, ORBM_EINVAL, "vocab_transform: %d is not a live vocabulary", vocab_id);
+    if (n < 0 || (n > 0 && (!desc || !word_id || !node_id))) return orbm_fail(ctx, ORBM_EINVAL, "vocab_transform: null argument or negative size");
+    if (n == 0) return ORBM_OK;
+    if (io_on_device && ((uintptr_t)desc & 15)) return orbm_fail(ctx, ORBM_EINVAL, "vocab_transform: device descriptors must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = orbm_ws_reserve(ctx, (size_t)n * 40 + 4096);
+    if (rc) return rc;
+    IoStage io(ctx, io_on_device);
+    const void *dd; void *dw, *dn;
+    if ((rc = io.in(desc, (size_t)n * 32, &dd)) || (rc = io.out(word_id, (size_t)n * 4, &dw)) || (rc = io.out(node_id, (size_t)n * 4, &dn)))
+        return rc;
+    hipLaunchKernelGGL(transform_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)dd, n,
+                       ctx->vocabs[vocab_id], levelsup, (int32_t *)dw, (int32_t *)dn);
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
+}

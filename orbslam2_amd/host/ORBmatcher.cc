@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/orbmatch.h"
+#include "host_ctx.h"
 #include "host_gates.h"
 
 using namespace std;
@@ -25,14 +26,18 @@ float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
 float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
 
 namespace {
+int g_device = -1;
+}
 
 // ---- one C-ABI context per calling thread (the reference calls the matcher from three threads) -------------
-int g_device = -1;
+namespace detail {
+namespace {
 struct ThreadCtx {
     orbm_ctx *ctx = nullptr;
     ~ThreadCtx() { if (ctx) orbm_destroy(ctx); }
 };
-orbm_ctx *Ctx() {
+}  // namespace
+orbm_ctx *HostCtx() {
     static thread_local ThreadCtx t;
     if (!t.ctx) {
         int dev = g_device;
@@ -42,9 +47,14 @@ orbm_ctx *Ctx() {
     }
     return t.ctx;
 }
-void Check(int rc, const char *what) {
-    if (rc < 0) throw runtime_error(string("ORBmatcher: ") + what + " failed: " + orbm_last_error(Ctx()));
+void HostCheck(int rc, const char *what) {
+    if (rc < 0) throw runtime_error(string("ORBmatcher: ") + what + " failed: " + orbm_last_error(HostCtx()));
 }
+}  // namespace detail
+
+namespace {
+orbm_ctx *Ctx() { return detail::HostCtx(); }
+void Check(int rc, const char *what) { detail::HostCheck(rc, what); }
 
 // ---- flat snapshots -----------------------------------------------------------------------------------------
 struct Flat {

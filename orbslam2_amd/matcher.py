@@ -124,6 +124,45 @@ class Context:
         ids = np.ascontiguousarray(ids, np.int32)
         self._chk(self._L.orbm_queries_free(self._h, len(ids), _addr(ids)))
 
+    # ---- DBoW2 transform (Frame::ComputeBoW / KeyFrame::ComputeBoW), FeatureVector kept on the device ----
+    def upload_vocabulary(self, vocab) -> int:
+        v = vocab.view()
+        vid = C.c_int32(-1)
+        self._chk(self._L.orbm_vocab_upload(self._h, C.byref(v), C.byref(vid)))
+        return int(vid.value)
+
+    def free_vocabulary(self, vid: int):
+        self._chk(self._L.orbm_vocab_free(self._h, int(vid)))
+
+    def compute_bow(self, vid: int, frames, levelsup: int = 4, stride: int = 0, want_ids: bool = True):
+        """-> (word_id, node_id) [n_frames, stride] when want_ids, else None; the frames' FeatureVectors are replaced."""
+        fr = np.ascontiguousarray(frames, np.int32)
+        p = len(fr)
+        if not want_ids:
+            self._chk(self._L.orbm_frames_compute_bow(self._h, int(vid), p, _addr(fr), int(levelsup), int(stride), None, None))
+            return None
+        word = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        node = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
+        self._chk(self._L.orbm_frames_compute_bow(self._h, int(vid), p, _addr(fr), int(levelsup), int(stride), _addr(word), _addr(node)))
+        return word[:p], node[:p]
+
+    def transform(self, vid: int, desc: np.ndarray, levelsup: int = 4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.full(max(n, 1), -1, np.int32)
+        node = np.full(max(n, 1), -1, np.int32)
+        self._chk(self._L.orbm_vocab_transform(self._h, int(vid), n, _addr(d) if n else None, int(levelsup), _addr(word), _addr(node), 0))
+        return word[:n], node[:n]
+
+    def feature_vector(self, fid: int, n: int):
+        fv_node = np.zeros(max(n, 1), np.uint32)
+        fv_off = np.zeros(n + 1, np.uint32)
+        fv_idx = np.zeros(max(n, 1), np.uint32)
+        nn = C.c_int32(0)
+        self._chk(self._L.orbm_frame_fv_download(self._h, int(fid), C.byref(nn), _addr(fv_node), _addr(fv_off), _addr(fv_idx)))
+        k = int(nn.value)
+        return fv_node[:k], fv_off[:k + 1], fv_idx[: int(fv_off[k])]
+
     # ---- a1 ----
     def hamming_pairs(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)

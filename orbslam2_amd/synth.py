@@ -271,3 +271,64 @@ def triang_pair(seed, n=2000, stereo_frac=0.3, has_mp_frac=0.5):
     f12 = (f12 + rng.normal(0, 2e-6, 9)).astype(np.float32)
     epipole = np.array([320.0 + rng.normal(0, 50), 240.0 + rng.normal(0, 50)], dtype=np.float32)
     return f1, f2, f12, epipole
+
+
+def make_vocabulary(seed=SEED0 + 9, k=10, depth=3, irregular=False, flip=0.2, tie_frac=0.0, stop_frac=0.0):
+    """Synthetic DBoW2-shaped vocabulary tree, breadth-first node ids (the order DBoW2 saves and loads), children of a
+    node = noisy copies of it (flip = per-bit flip probability) so that descents are decisive at the top and close at
+    the bottom.  irregular: 1..k children per node and leaves above the last level (k-means clusters that could not be
+    split).  tie_frac: fraction of nodes whose descriptor is copied from their elder sibling (exact distance ties: the
+    first child must win).  stop_frac: fraction of words with weight 0 (left out of the FeatureVector)."""
+    from .views import VocabData
+    rng = np.random.default_rng(seed)
+    desc = [np.zeros(32, np.uint8)]
+    level = [0]
+    children = [[]]
+    frontier = [0]
+    for lv in range(1, depth + 1):
+        nxt = []
+        for parent in frontier:
+            if irregular and lv > 1 and rng.random() < 0.15:
+                continue                                     # stays a leaf above the last level
+            nc = int(rng.integers(1, k + 1)) if irregular else k
+            base = desc[parent] if lv > 1 else None
+            for c in range(nc):
+                if base is None:
+                    d = rng.integers(0, 256, 32, dtype=np.uint8)
+                else:
+                    bits = np.unpackbits(base)
+                    bits ^= (rng.random(256) < flip).astype(np.uint8)
+                    d = np.packbits(bits)
+                if c > 0 and rng.random() < tie_frac:
+                    d = desc[children[parent][c - 1]].copy()
+                nid = len(desc)
+                desc.append(d)
+                level.append(lv)
+                children.append([])
+                children[parent].append(nid)
+                nxt.append(nid)
+        frontier = nxt
+    n_nodes = len(desc)
+    child_off = np.zeros(n_nodes + 1, np.uint32)
+    child_idx = []
+    word_id = np.full(n_nodes, -1, np.int32)
+    nw = 0
+    for i in range(n_nodes):
+        child_off[i + 1] = child_off[i] + len(children[i])
+        child_idx.extend(children[i])
+        if not children[i]:
+            word_id[i] = nw
+            nw += 1
+    weight = rng.random(n_nodes) * 5 + 0.01
+    weight[rng.random(n_nodes) < stop_frac] = 0.0
+    return VocabData(depth=depth, child_off=child_off, child_idx=np.asarray(child_idx, np.uint32), desc=np.stack(desc),
+                     word_id=word_id, weight=weight)
+
+
+def vocabulary_features(rng, vocab, n, flip=0.1):
+    """n descriptors near random nodes of the tree (so descents meet close calls), plus a few exact node descriptors."""
+    pick = rng.integers(1, vocab.n_nodes, n)
+    bits = np.unpackbits(vocab.desc[pick], axis=1)
+    noisy = bits ^ (rng.random(bits.shape) < flip).astype(np.uint8)
+    noisy[: n // 8] = bits[: n // 8]
+    return np.packbits(noisy, axis=1)

@@ -77,6 +77,18 @@ class CWinQueries(C.Structure):
     ]
 
 
+class CVocabView(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int32),
+        ("depth", C.c_int32),
+        ("child_off", _u32p),
+        ("child_idx", _u32p),
+        ("desc", _u8p),
+        ("word_id", _i32p),
+        ("weight", C.POINTER(C.c_double)),
+    ]
+
+
 def _ptr(a: Optional[np.ndarray], ctype):
     if a is None:
         return C.cast(None, C.POINTER(ctype))
@@ -232,3 +244,32 @@ class WinQueries:
                         flags=_ptr(self.flags, C.c_uint8))
         w._owner = self
         return w
+
+
+@dataclass
+class VocabData:
+    """Flat DBoW2 vocabulary tree (orbm_vocab_view): node 0 = root, children of node i = child_idx[child_off[i]:child_off[i+1]]."""
+    depth: int
+    child_off: np.ndarray   # [n_nodes+1] uint32
+    child_idx: np.ndarray   # uint32
+    desc: np.ndarray        # [n_nodes,32] uint8
+    word_id: np.ndarray     # [n_nodes] int32, -1 for inner nodes
+    weight: Optional[np.ndarray] = None   # [n_nodes] float64
+
+    def __post_init__(self):
+        self.child_off = _as(self.child_off, np.uint32)
+        self.child_idx = _as(self.child_idx, np.uint32)
+        self.desc = _as(self.desc, np.uint8).reshape(-1, 32)
+        self.word_id = _as(self.word_id, np.int32)
+        self.weight = _as(self.weight, np.float64)
+
+    @property
+    def n_nodes(self) -> int:
+        return int(self.desc.shape[0])
+
+    def view(self) -> CVocabView:
+        v = CVocabView(n_nodes=self.n_nodes, depth=int(self.depth), child_off=_ptr(self.child_off, C.c_uint32),
+                       child_idx=_ptr(self.child_idx, C.c_uint32), desc=_ptr(self.desc, C.c_uint8),
+                       word_id=_ptr(self.word_id, C.c_int32), weight=_ptr(self.weight, C.c_double))
+        v._owner = self
+        return v

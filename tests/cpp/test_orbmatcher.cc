@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <memory>
 #include <random>
 #include <set>
@@ -13,6 +14,7 @@
 
 #include "../../include/orbmatch.h"
 #include "../../orbslam2_amd/host/ORBmatcher.h"
+#include "../../orbslam2_amd/host/ORBVocabulary.h"
 #include "../../orbslam2_amd/host/host_gates.h"
 
 using namespace ORB_SLAM2;
@@ -26,6 +28,7 @@ int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries
 int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int chi2_gate, int32_t *best_idx, uint64_t *ncmp);
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize, float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp);
 int orc_distinctive_descriptor(const uint8_t *desc, int n);
+int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx);
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels);
 }
 
@@ -649,6 +652,111 @@ static void TestDistinctive() {
     printf("ComputeDistinctiveDescriptorsBatch done\n");
 }
 
+// ORBVocabulary: text file -> loadFromTextFile -> transform (descent on the GPU) against the restated DBoW2 descent on
+// the same flat tree; BowVector against a direct accumulation; L1 score against 1 - ||a - b||_1 / 2.
+static void TestVocabulary() {
+    const int k = 8, L = 3;
+    struct N { int parent; bool leaf; Desc d; double w; };
+    vector<N> nodes;                       // file order = breadth first
+    vector<int> frontier = {0};
+    vector<Desc> of = {Desc()};            // descriptor per node id (0 = root, unused)
+    for (int lv = 1; lv <= L; lv++) {
+        vector<int> next;
+        for (int p : frontier)
+            for (int c = 0; c < k; c++) {
+                N nd; nd.parent = p; nd.leaf = lv == L; nd.d = lv == 1 ? RandDesc() : Observe(of[p], 0.18);
+                if (c > 0 && U(0, 1) < 0.1) nd.d = of.back();                       // exact tie with the elder sibling
+                nd.w = U(0, 1) < 0.1 ? 0.0 : U(0.01, 6.0);
+                nodes.push_back(nd); of.push_back(nd.d); next.push_back((int)nodes.size());
+            }
+        frontier = next;
+    }
+    char path[256];
+    snprintf(path, sizeof path, "/tmp/orbm_test_voc_%ld.txt", (long)rng() % 1000000);
+    {
+        std::ofstream f(path);
+        f << k << " " << L << " " << 0 << " " << 0 << "\n";                      // L1_NORM, TF_IDF (as ORBvoc.txt)
+        f.precision(17);
+        for (auto &nd : nodes) {
+            f << nd.parent << " " << (nd.leaf ? 1 : 0) << " ";
+            for (int j = 0; j < 32; j++) f << (int)nd.d.b[j] << " ";
+            f << nd.w << "\n";                                                  // the file ends with a newline
+        }
+    }
+    ORBVocabulary voc;
+    EXPECT(!voc.loadFromTextFile("/nonexistent/voc.txt"), "missing file must fail");
+    EXPECT(voc.loadFromTextFile(path), "loadFromTextFile");
+    remove(path);
+    EXPECT((int)voc.size() == k * k * k, "size %u", voc.size());
+    const auto &T = voc.flat();
+    const int nn = (int)T.word_id.size();
+    EXPECT(nn == (int)nodes.size() + 2, "nodes %d: root + lines + the loader's end-of-file node", nn);
+    EXPECT(T.child_off[1] == (uint32_t)k + 1 && T.child_idx[k] == (uint32_t)nn - 1 && T.weight[nn - 1] == 0.0, "end-of-file node");
+    orbm_vocab_view V;
+    V.n_nodes = nn; V.depth = L; V.child_off = T.child_off.data(); V.child_idx = T.child_idx.data(); V.desc = T.desc.data();
+    V.word_id = T.word_id.data(); V.weight = T.weight.data();
+
+    for (int levelsup : {4, 1, 2, 0}) {
+        const int n = 1500;
+        vector<Desc> feat(n);
+        for (int i = 0; i < n; i++) feat[i] = Observe(of[1 + RI((int)nodes.size())], i % 7 == 0 ? 0.0 : 0.1);
+        memset(feat[5].b, 0, 32);                                               // falls into the end-of-file node: weight 0, left out
+        vector<cv::Mat> rows(n);
+        for (int i = 0; i < n; i++) { rows[i] = cv::Mat(1, 32, CV_8U); memcpy(rows[i].ptr<uint8_t>(), feat[i].b, 32); }
+        DBoW2::BowVector bv;
+        DBoW2::FeatureVector fv;
+        bv[12345] = 1.0; fv[7].push_back(3);                                    // transform() clears its outputs
+        double t0 = NowMs();
+        voc.transform(rows, bv, fv, levelsup);
+        double t1 = NowMs();
+        vector<int32_t> word(n), node(n);
+        vector<uint32_t> fn(n), fo(n + 1), fi(n);
+        const int nfn = orc_transform(&V, feat[0].b, n, levelsup, word.data(), node.data(), fn.data(), fo.data(), fi.data());
+        EXPECT(node[5] == -1, "the all-zero feature must be left out (node %d)", node[5]);
+        EXPECT((int)fv.size() == nfn, "levelsup %d: %zu nodes vs %d", levelsup, fv.size(), nfn);
+        int bad = 0, j = 0;
+        for (auto &kv : fv) {
+            if (j >= nfn || kv.first != fn[j] || kv.second.size() != fo[j + 1] - fo[j]) { bad++; j++; continue; }
+            for (size_t t = 0; t < kv.second.size(); t++) bad += kv.second[t] != fi[fo[j] + t];
+            j++;
+        }
+        EXPECT(bad == 0, "levelsup %d: %d FeatureVector mismatches", levelsup, bad);
+        // BowVector: sum of the word weights in feature order, then L1-normalised in word order
+        std::map<unsigned, double> want;
+        for (int i = 0; i < n; i++) if (node[i] >= 0) {
+            double w = 0; for (int q = 0; q < nn; q++) if (T.word_id[q] == word[i] && T.child_off[q + 1] == T.child_off[q] && q != nn - 1) w = T.weight[q];
+            auto it = want.find((unsigned)word[i]);
+            if (it == want.end()) want[(unsigned)word[i]] = w; else it->second += w;
+        }
+        double norm = 0; for (auto &kv : want) norm += std::fabs(kv.second);
+        for (auto &kv : want) kv.second /= norm;
+        int bvbad = bv.size() != want.size();
+        for (auto &kv : want) { auto it = bv.find(kv.first); bvbad += it == bv.end() || it->second != kv.second; }
+        EXPECT(bvbad == 0, "levelsup %d: %d BowVector mismatches", levelsup, bvbad);
+        if (levelsup == 4) {
+            EXPECT(fv.size() == 1 && fv.begin()->first == 0, "levelsup above the depth: everything in the root");
+            printf("ORBVocabulary::transform, %d features, k=%d L=%d: %.2f ms (first call uploads the tree)\n", n, k, L, t1 - t0);
+            t0 = NowMs(); for (int r = 0; r < 20; r++) voc.transform(rows, bv, fv, levelsup); t1 = NowMs();
+            printf("ORBVocabulary::transform: %.3f ms per call afterwards\n", (t1 - t0) / 20);
+        }
+        // score
+        DBoW2::BowVector other;
+        vector<cv::Mat> half(rows.begin(), rows.begin() + n / 2);
+        DBoW2::FeatureVector fv2;
+        voc.transform(half, other, fv2, levelsup);
+        double l1 = 0;
+        { std::set<unsigned> keys; for (auto &kv : bv) keys.insert(kv.first); for (auto &kv : other) keys.insert(kv.first);
+          for (unsigned key : keys) { double a = bv.count(key) ? bv[key] : 0, b = other.count(key) ? other[key] : 0; l1 += std::fabs(a - b); } }
+        const double sc = voc.score(bv, other);
+        EXPECT(std::fabs(sc - (1.0 - 0.5 * l1)) < 1e-12 && sc > 0.2 && sc < 1.0, "score %.15f vs %.15f", sc, 1.0 - 0.5 * l1);
+        EXPECT(std::fabs(voc.score(bv, bv) - 1.0) < 1e-12, "self score");
+    }
+    DBoW2::BowVector e1; DBoW2::FeatureVector e2;
+    voc.transform(vector<cv::Mat>(), e1, e2, 4);
+    EXPECT(e1.empty() && e2.empty(), "no features");
+    printf("ORBVocabulary done\n");
+}
+
 int main() {
     try {
         // a1 helper
@@ -664,6 +772,7 @@ int main() {
         TestSim3();
         TestFuse();
         TestDistinctive();
+        TestVocabulary();
     } catch (const std::exception &e) {
         printf("EXCEPTION: %s\n", e.what());
         return 2;

@@ -582,3 +582,109 @@ def test_all_pairs_end_to_end_on_one_gpu(ctx, orc):
         tot += wc
     assert tot > 2000
     ctx.free_frames(ids)
+
+
+def _vocab_cases():
+    return [dict(k=10, depth=3), dict(k=10, depth=4, flip=0.12), dict(k=6, depth=5, irregular=True, tie_frac=0.2),
+            dict(k=3, depth=6, irregular=True, tie_frac=0.3, stop_frac=0.2), dict(k=2, depth=1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(5))
+def test_vocabulary_transform_parity(ctx, orc, case):
+    """DBoW2 transform on the device (Frame::ComputeBoW / KeyFrame::ComputeBoW): word ids, node ids and the FeatureVector
+    left in the frame, against the restated DBoW2 descent; regular and irregular trees, exact ties between siblings,
+    stopped words, levelsup from the leaves to above the root, empty frames, frames of different sizes in one call."""
+    kw = _vocab_cases()[case]
+    vocab = synth.make_vocabulary(seed=500 + case, **kw)
+    rng = np.random.default_rng(900 + case)
+    sizes = [2000, 1, 0, 257, 1023, 4096 if case == 0 else 700]
+    frames = []
+    for n in sizes:
+        d = synth.vocabulary_features(rng, vocab, n) if n else np.zeros((0, 32), np.uint8)
+        frames.append(synth.make_frame(rng, d, np.arange(n), p_flip=0.0, with_fv=(n == 257)))   # one arrives with a host FV
+    ids = ctx.upload_frames(frames)
+    vid = ctx.upload_vocabulary(vocab)
+    try:
+        for levelsup in ([4, 0, 1, 2, vocab.depth, vocab.depth + 3] if case < 3 else [4, 1]):
+            word, node = ctx.compute_bow(vid, ids, levelsup, stride=max(sizes))
+            for k, f in enumerate(frames):
+                w_want, n_want, (fn, fo, fi) = orc.transform(vocab, f.desc, levelsup)
+                assert np.array_equal(word[k, :f.n], w_want), (case, levelsup, k)
+                assert np.array_equal(node[k, :f.n], n_want), (case, levelsup, k)
+                assert (word[k, f.n:] == -1).all() and (node[k, f.n:] == -1).all()
+                gn, go, gi = ctx.feature_vector(ids[k], f.n)
+                assert np.array_equal(gn, fn) and np.array_equal(go, fo) and np.array_equal(gi, fi), (case, levelsup, k)
+                if k < 2 or f.n == 0:                      # the same descent on bare descriptors
+                    w2, n2 = ctx.transform(vid, f.desc, levelsup)
+                    assert np.array_equal(w2, w_want) and np.array_equal(n2, n_want)
+        # the same call without the id outputs leaves the same FeatureVectors
+        ctx.compute_bow(vid, ids[:2], 2, want_ids=False)
+        _, _, (fn, fo, fi) = orc.transform(vocab, frames[0].desc, 2)
+        gn, go, gi = ctx.feature_vector(ids[0], frames[0].n)
+        assert np.array_equal(gn, fn) and np.array_equal(go, fo) and np.array_equal(gi, fi)
+    finally:
+        ctx.free_vocabulary(vid)
+        ctx.free_frames(ids)
+
+
+@pytest.mark.gpu
+def test_search_bow_on_device_built_feature_vectors(ctx, orc):
+    """Keyframes uploaded WITHOUT a FeatureVector, ComputeBoW on the device, then SearchByBoW: the matches equal the
+    oracle's on frames that carry the FeatureVector the restated DBoW2 builds on the host."""
+    vocab = synth.make_vocabulary(seed=61, k=10, depth=5, flip=0.15)
+    rng = np.random.default_rng(62)
+    lm = synth.vocabulary_features(rng, vocab, 3000, flip=0.05)
+    frames = []
+    for _ in range(6):
+        sel = rng.permutation(3000)[:1500]
+        flags = np.where(rng.random(1500) < 0.9, MP_PRESENT, 0).astype(np.uint8)
+        frames.append(synth.make_frame(rng, lm, sel, with_fv=False, mp_flags=flags))
+    ids = ctx.upload_frames(frames)
+    vid = ctx.upload_vocabulary(vocab)
+    try:
+        ctx.compute_bow(vid, ids, 4, want_ids=False)
+        for f in frames:
+            _, _, (f.fv_node, f.fv_off, f.fv_idx) = orc.transform(vocab, f.desc, 4)
+        pa = np.array([0, 0, 1, 2, 3, 4], np.int32); pb = np.array([1, 2, 3, 4, 5, 5], np.int32)
+        for variant in (0, 1):
+            counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=1500)
+            for p in range(len(pa)):
+                cnt, m, _ = orc.search_bow(variant, frames[pa[p]], frames[pb[p]], 0.75, True)
+                assert counts[p] == cnt and np.array_equal(match[p, :frames[pa[p]].n], m), (variant, p)
+            assert counts.sum() > 100
+    finally:
+        ctx.free_vocabulary(vid)
+        ctx.free_frames(ids)
+
+
+@pytest.mark.gpu
+def test_vocabulary_errors(ctx):
+    from orbslam2_amd.matcher import OrbmError
+    from orbslam2_amd.views import VocabData
+    good = synth.make_vocabulary(seed=5, k=3, depth=2)
+    bad_child = VocabData(depth=good.depth, child_off=good.child_off, child_idx=good.child_idx.copy(), desc=good.desc, word_id=good.word_id)
+    bad_child.child_idx[2] = 0                                  # a child that is not a later node: the descent could loop
+    with pytest.raises(OrbmError):
+        ctx.upload_vocabulary(bad_child)
+    no_word = VocabData(depth=good.depth, child_off=good.child_off, child_idx=good.child_idx, desc=good.desc, word_id=np.full(good.n_nodes, -1))
+    with pytest.raises(OrbmError):
+        ctx.upload_vocabulary(no_word)
+    rng = np.random.default_rng(1)
+    ids = ctx.upload_frames([synth.make_frame(rng, synth.random_descriptors(rng, 10), np.arange(10), with_fv=False)])
+    vid = ctx.upload_vocabulary(good)
+    with pytest.raises(OrbmError):
+        ctx.compute_bow(vid + 7, ids, 4, stride=10)
+    with pytest.raises(OrbmError):
+        ctx.compute_bow(vid, [ids[0], ids[0]], 4, stride=10)    # a frame listed twice
+    with pytest.raises(OrbmError):
+        ctx.compute_bow(vid, ids, 4, stride=5)                  # stride below the frame size
+    ctx.free_vocabulary(vid)
+    with pytest.raises(OrbmError):
+        ctx.compute_bow(vid, ids, 4, stride=10)                 # freed
+    word, node = None, None
+    vid = ctx.upload_vocabulary(good)
+    word, node = ctx.compute_bow(vid, ids, 4, stride=10)        # the context still works
+    assert (word >= 0).all() and (node == 0).all()
+    ctx.free_vocabulary(vid)
+    ctx.free_frames(ids)

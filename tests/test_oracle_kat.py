@@ -214,3 +214,39 @@ def test_distinctive_descriptor_known_answers(orc):
     assert orc.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
     # N = 4, median index (int)1.5 = 1: rows of {a, a, b, c}: a: [0,0,1,256] -> 0; b: [0,1,1,255] -> 1; c -> 255
     assert orc.distinctive_descriptor(np.stack([b, c, a, a])) == 2
+
+
+def _tiny_vocab(weight=None):
+    """k = 2, L = 2 by hand: root 0 -> {1: 0x00.., 2: 0xFF..}; 1 -> {3: 0x00.., 4: 0x0F in byte 0}; 2 -> {5: 0xFF.., 6: 0xFF..}
+    (5 and 6 identical: every descent below 2 ties, the first child 5 must win).  Words: 3->0, 4->1, 5->2, 6->3."""
+    from orbslam2_amd.views import VocabData
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8); n4 = z.copy(); n4[0] = 0x0F
+    return VocabData(depth=2, child_off=[0, 2, 4, 6, 6, 6, 6, 6], child_idx=[1, 2, 3, 4, 5, 6],
+                     desc=np.stack([z, z, o, z, n4, o, o]), word_id=[-1, -1, -1, 0, 1, 2, 3], weight=weight)
+
+
+def test_vocabulary_transform_known_answers(orc):
+    """DBoW2 transform by hand on the tiny tree: feature 0x00.. -> node 1 then leaf 3 (word 0); 0x07 in byte 0 -> node 1,
+    distances 3 vs 1 -> leaf 4 (word 1); 0x03 in byte 0 -> distances 2 vs 2: tie, first child 3 (word 0); 0xFF.. -> node 2,
+    tie -> leaf 5 (word 2); 128 ones in bytes 0..15 -> root tie (128 vs 128) -> node 1, then 128 vs 124 -> leaf 4 (word 1).  levelsup = 1 -> node ids at level 1; levelsup = 0 -> the
+    leaves; levelsup >= 2 -> the root (one node holding every feature)."""
+    v = _tiny_vocab()
+    f = np.zeros((5, 32), np.uint8)
+    f[1, 0] = 0x07; f[2, 0] = 0x03; f[3] = 255; f[4, :16] = 255
+    word, node, (fn, fo, fi) = orc.transform(v, f, 1)
+    assert word.tolist() == [0, 1, 0, 2, 1]
+    assert node.tolist() == [1, 1, 1, 2, 1]
+    assert fn.tolist() == [1, 2] and fo.tolist() == [0, 4, 5] and fi.tolist() == [0, 1, 2, 4, 3]
+    word, node, (fn, fo, fi) = orc.transform(v, f, 0)
+    assert node.tolist() == [3, 4, 3, 5, 4]
+    assert fn.tolist() == [3, 4, 5] and fo.tolist() == [0, 2, 4, 5] and fi.tolist() == [0, 2, 1, 4, 3]
+    for up in (2, 3, 7):
+        word, node, (fn, fo, fi) = orc.transform(v, f, up)
+        assert node.tolist() == [0] * 5 and fn.tolist() == [0] and fo.tolist() == [0, 5] and fi.tolist() == [0, 1, 2, 3, 4]
+    # a word of weight 0 is "stopped": its features are in no node (transform(): if (w > 0))
+    w = np.ones(7); w[3] = 0.0
+    word, node, (fn, fo, fi) = orc.transform(_tiny_vocab(w), f, 1)
+    assert word.tolist() == [0, 1, 0, 2, 1] and node.tolist() == [-1, 1, -1, 2, 1]
+    assert fn.tolist() == [1, 2] and fo.tolist() == [0, 2, 3] and fi.tolist() == [1, 4, 3]
+    word, node, (fn, fo, fi) = orc.transform(v, np.zeros((0, 32), np.uint8), 1)
+    assert len(word) == 0 and len(fn) == 0 and fo.tolist() == [0]
