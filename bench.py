@@ -89,9 +89,14 @@ def cpu_baseline(kfs, seconds=12.0):
     t1 = time.perf_counter()
     orc.search_proj_points(f, q, 3.0, 0.8)
     proj_ms = (time.perf_counter() - t1) * 1e3
+    # ComputeBoW of one frame on one core (descent of the synthetic k = 10, depth-6 tree; restated DBoW2 transform)
+    voc = synth.make_vocabulary_regular()
+    t1 = time.perf_counter()
+    orc.transform(voc, kfs[0].desc, 4)
+    bow_ms = (time.perf_counter() - t1) * 1e3
     return {"value": round(multi / 1e9, 4), "unit": "G Hamming cmps/s", "cores": cores, "kind": "port",
             "single_thread_value": round(single / 1e9, 4), "single_thread_hw_popcnt_value": round(single_popcnt / 1e9, 4),
-            "search_by_projection_single_instance_ms": round(proj_ms, 3),
+            "search_by_projection_single_instance_ms": round(proj_ms, 3), "compute_bow_single_frame_ms": round(bow_ms, 3),
             "sample": f"{sum(done)} random keyframe pairs of the bench store ({N_FEAT}x{N_FEAT} brute-force 2-NN, SWAR popcount "
                       f"as ORBmatcher.cc:2184-2200), {cores} threads x {seconds * 0.75:.0f} s; single thread {n1} pairs"}
 
@@ -177,6 +182,22 @@ def secondary(ctx, torch, dev, kfs, ids):
         else:
             out["search_by_projection_single_instance_ms"] = round(best, 4)
     ctx.free_frames(fid); ctx.free_queries(qid)
+    # ComputeBoW on the device: descent of a k = 10, depth-6 tree (ORBvoc.txt's shape, 1.1 M nodes, synthetic) with every
+    # descriptor of the store's keyframes + FeatureVector build, in one call; then one frame alone
+    import time
+    vid = ctx.upload_vocabulary(synth.make_vocabulary_regular())
+    for nfr in (len(ids), 1):
+        best = 1e30
+        for rep in range(4):
+            ctx.synchronize(); t0 = time.perf_counter()
+            ctx.compute_bow(vid, ids[:nfr], 4, want_ids=False)
+            ctx.synchronize(); best = min(best, time.perf_counter() - t0) if rep else best
+        if nfr > 1:
+            out["compute_bow_features_per_s"] = round(nfr * N_FEAT / best, 1)
+        else:
+            out["compute_bow_single_frame_ms"] = round(best * 1e3, 4)
+    ctx.free_vocabulary(vid)
+    # the store's keyframes got FeatureVectors of the synthetic tree: nothing after this point uses them
     return out
 
 

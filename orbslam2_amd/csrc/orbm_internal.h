@@ -48,11 +48,14 @@ struct Arena {
     int live = 0;       // objects still referencing it
 };
 
-// Device-resident vocabulary tree (DBoW2 TemplatedVocabulary): node 0 is the root, children of node i are
-// child_idx[child_off[i] .. child_off[i+1]) in stored order, 32-byte descriptor per node, word id per leaf (-1 inside).
+// Device-resident vocabulary tree (DBoW2 TemplatedVocabulary): node 0 is the root.  node_rec[i] = {x, y}: y & 0x7FFFFFFF =
+// number of children (0 = leaf); y bit 31 set: the children have consecutive ids starting at x (breadth-first files,
+// the common case: no index load); clear: they are child_idx[x .. x + count) in stored order.  32-byte descriptor per
+// node, word id per leaf (-1 inside; bit 31 = the word's weight is not positive).
 struct VocabDev {
     int32_t n_nodes = 0, depth = 0;
-    const uint32_t *child_off = nullptr, *child_idx = nullptr, *desc = nullptr;
+    const uint2 *node_rec = nullptr;
+    const uint32_t *child_idx = nullptr, *desc = nullptr;
     const int32_t *word_id = nullptr;
     Arena arena;
 };

@@ -17,60 +17,142 @@ namespace {
 
 constexpr int FV_MAX_N = 8192;     // features per frame the LDS sort holds (64 KB of 8-byte keys)
 
-// one descriptor down the tree -> {word id | stopped << 31, node id at level depth - levelsup}
-__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ g, int levelsup, int32_t &word, int &nid) {
-    const uint4 lo = g[0], hi = g[1];
-    const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const int nid_level = V.depth - levelsup;
-    nid = 0;                                       // nid_level <= 0: the root
-    uint32_t final_id = 0;
-    int level = 0;
-    for (;;) {
-        const uint32_t b = V.child_off[final_id], e = V.child_off[final_id + 1];
-        if (b == e) break;                         // leaf
-        ++level;
-        uint32_t best_id = 0, best_d = 0xFFFFFFFFu;
-        for (uint32_t c = b; c < e; c++) {
-            const uint32_t id = V.child_idx[c];
-            const uint4 *cg = reinterpret_cast<const uint4 *>(V.desc) + 2 * (size_t)id;
-            const uint4 clo = cg[0], chi = cg[1];
-            const uint32_t cd[8] = {clo.x, clo.y, clo.z, clo.w, chi.x, chi.y, chi.z, chi.w};
-            const uint32_t d = hamming256(q, cd);
-            if (d < best_d) { best_d = d; best_id = id; }          // strict '<': the first child wins ties
-        }
-        final_id = best_id;
-        if (level == nid_level) nid = (int)final_id;
+constexpr int VOC_GROUP = 16;      // lanes per feature: one child each per pass (k = 10 in ORBvoc.txt)
+constexpr int VOC_MAX_CHILDREN = 65535;
+
+// NF descriptors down the tree per 16-lane group -> {word id | stopped << 31, node id at level depth - levelsup} each.
+// Lane `sub` of a group takes child sub, sub + 16, ...: the 32-byte rows of a node's children are adjacent in memory when
+// ids are breadth-first, so a group's loads touch 3 cache lines per level instead of one line per lane and child.
+// The least (distance << 16 | child position) over the group is DBoW2's choice: strict '<' over the children in stored
+// order = the first child among equals.  A level is two dependent loads (node record, child rows) and the kernel is
+// bound by that latency: NF independent descents per group keep NF times as many loads in flight.  Control flow is
+// wave-uniform (descents that reached a leaf idle until the whole wave has), loads of lanes without a child go to
+// row 0, so the cross-lane steps never read a lane that sits out.
+template <int NF>
+__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ const (&g)[NF], int levelsup, int32_t (&word)[NF], int (&nid)[NF]) {
+    const uint32_t sub = threadIdx.x & (VOC_GROUP - 1);
+    uint32_t q[NF][8];
+#pragma unroll
+    for (int u = 0; u < NF; u++) {
+        const uint4 lo = g[u][0], hi = g[u][1];
+        q[u][0] = lo.x; q[u][1] = lo.y; q[u][2] = lo.z; q[u][3] = lo.w; q[u][4] = hi.x; q[u][5] = hi.y; q[u][6] = hi.z; q[u][7] = hi.w;
     }
-    word = V.word_id[final_id];                    // bit 31: the word's weight is not positive
+    const int nid_level = V.depth - levelsup;
+    uint32_t final_id[NF];
+    int level[NF];
+#pragma unroll
+    for (int u = 0; u < NF; u++) { nid[u] = 0; final_id[u] = 0; level[u] = 0; }       // nid_level <= 0: the root
+    for (;;) {
+        uint2 rec[NF];
+        uint32_t cnt[NF], maxcnt = 0;
+        bool all_contiguous = true;
+#pragma unroll
+        for (int u = 0; u < NF; u++) {
+            rec[u] = V.node_rec[final_id[u]];
+            cnt[u] = rec[u].y & 0x7FFFFFFFu;
+            maxcnt = max(maxcnt, cnt[u]);
+            all_contiguous = all_contiguous && (cnt[u] == 0 || (rec[u].y >> 31) != 0);
+        }
+        if (__all(maxcnt == 0)) break;             // every descent of the wave is at a leaf
+        const bool wave_contiguous = __all(all_contiguous);
+        uint32_t best[NF];
+#pragma unroll
+        for (int u = 0; u < NF; u++) best[u] = 0xFFFFFFFFu;
+        for (uint32_t c0 = 0; __any(c0 < maxcnt); c0 += VOC_GROUP) {
+            const uint32_t j = c0 + sub;
+            uint32_t id[NF];
+#pragma unroll
+            for (int u = 0; u < NF; u++) id[u] = j < cnt[u] ? rec[u].x + j : 0u;
+            if (!wave_contiguous) {
+#pragma unroll
+                for (int u = 0; u < NF; u++)
+                    if (j < cnt[u] && (rec[u].y >> 31) == 0) id[u] = V.child_idx[id[u]];
+            }
+            uint4 clo[NF], chi[NF];
+#pragma unroll
+            for (int u = 0; u < NF; u++) {
+                const uint4 *cg = reinterpret_cast<const uint4 *>(V.desc) + 2 * (size_t)id[u];
+                clo[u] = cg[0]; chi[u] = cg[1];
+            }
+#pragma unroll
+            for (int u = 0; u < NF; u++) {
+                const uint32_t cd[8] = {clo[u].x, clo[u].y, clo[u].z, clo[u].w, chi[u].x, chi[u].y, chi[u].z, chi[u].w};
+                const uint32_t key = (hamming256(q[u], cd) << 16) | j;
+                best[u] = min(best[u], j < cnt[u] ? key : 0xFFFFFFFFu);
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < VOC_GROUP; m <<= 1) {
+#pragma unroll
+            for (int u = 0; u < NF; u++) best[u] = min(best[u], (uint32_t)__shfl_xor((int)best[u], m, VOC_GROUP));
+        }
+#pragma unroll
+        for (int u = 0; u < NF; u++)
+            if (cnt[u] != 0) {
+                const uint32_t j = best[u] & 0xFFFFu;
+                final_id[u] = (rec[u].y >> 31) ? rec[u].x + j : V.child_idx[rec[u].x + j];
+                ++level[u];
+                if (level[u] == nid_level) nid[u] = (int)final_id[u];
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < NF; u++) word[u] = V.word_id[final_id[u]];       // bit 31: the word's weight is not positive
 }
 
+template <int NF>
 __global__ __launch_bounds__(256) void transform_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ ids,
                                                         VocabDev V, int levelsup, int blocks_per_frame, int stride,
                                                         int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
     const int f = blockIdx.x / blocks_per_frame;
-    const int i = (blockIdx.x - f * blocks_per_frame) * 256 + (int)threadIdx.x;
+    const int i0 = ((blockIdx.x - f * blocks_per_frame) * (256 / VOC_GROUP) + (int)(threadIdx.x / VOC_GROUP)) * NF;
     const FrameDev &F = table[ids[f]];
-    if (i >= F.n) return;
-    int32_t w; int nid;
-    descend(V, reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)i, levelsup, w, nid);
-    word_out[(size_t)f * stride + i] = w & 0x7FFFFFFF;
-    node_out[(size_t)f * stride + i] = w < 0 ? -1 : nid;
+    const int n = F.n;
+    if (n == 0) return;                            // block-uniform
+    const uint4 *g[NF];
+#pragma unroll
+    for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)min(i0 + u, n - 1);
+    int32_t w[NF]; int nid[NF];
+    descend<NF>(V, g, levelsup, w, nid);
+    const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
+#pragma unroll
+    for (int u = 0; u < NF; u++)
+        if (sub == u && i0 + u < n) {
+            word_out[(size_t)f * stride + i0 + u] = w[u] & 0x7FFFFFFF;
+            node_out[(size_t)f * stride + i0 + u] = w[u] < 0 ? -1 : nid[u];
+        }
 }
 
+template <int NF>
 __global__ __launch_bounds__(256) void transform_flat_kernel(const uint32_t *__restrict__ desc, int n, VocabDev V, int levelsup,
                                                              int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
-    const int i = blockIdx.x * 256 + (int)threadIdx.x;
-    if (i >= n) return;
-    int32_t w; int nid;
-    descend(V, reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)i, levelsup, w, nid);
-    word_out[i] = w & 0x7FFFFFFF;
-    node_out[i] = w < 0 ? -1 : nid;
+    const int i0 = (blockIdx.x * (256 / VOC_GROUP) + (int)(threadIdx.x / VOC_GROUP)) * NF;
+    const uint4 *g[NF];
+#pragma unroll
+    for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)min(i0 + u, n - 1);
+    int32_t w[NF]; int nid[NF];
+    descend<NF>(V, g, levelsup, w, nid);
+    const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
+#pragma unroll
+    for (int u = 0; u < NF; u++)
+        if (sub == u && i0 + u < n) {
+            word_out[i0 + u] = w[u] & 0x7FFFFFFF;
+            node_out[i0 + u] = w[u] < 0 ? -1 : nid[u];
+        }
 }
 
-__global__ __launch_bounds__(256) void fv_build_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int stride,
-                                                       const int32_t *__restrict__ node_in, int32_t *__restrict__ n_nodes_out) {
+// descents per 16-lane group: 4 once there is enough work to fill the chip either way
+int g_vocab_variant = 0;      // test knob: 0 = by size, 1 / 4 = that many descents per group
+inline int descents_per_group(size_t total_features) {
+    if (g_vocab_variant == 1 || g_vocab_variant == 4) return g_vocab_variant;
+    return total_features >= (size_t)256 * 1024 ? 4 : 1;
+}
+
+constexpr int FVB_THREADS = 1024;
+
+__global__ __launch_bounds__(FVB_THREADS) void fv_build_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int stride,
+                                                               const int32_t *__restrict__ node_in, int32_t *__restrict__ n_nodes_out) {
     extern __shared__ __align__(16) unsigned long long keys[];
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[FVB_THREADS];
     __shared__ int n_in;
     const int f = blockIdx.x, tid = threadIdx.x;
     FrameDev &F = table[ids[f]];
@@ -80,7 +162,7 @@ __global__ __launch_bounds__(256) void fv_build_kernel(FrameDev *__restrict__ ta
     if (tid == 0) n_in = 0;
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += FVB_THREADS) {
         const int node = i < n_feat ? node_in[(size_t)f * stride + i] : -1;
         keys[i] = node >= 0 ? ((unsigned long long)(uint32_t)node << 32) | (uint32_t)i : ~0ull;     // left out: sorts last
         mine += node >= 0;
@@ -88,30 +170,34 @@ __global__ __launch_bounds__(256) void fv_build_kernel(FrameDev *__restrict__ ta
     if (mine) atomicAdd(&n_in, mine);
     __syncthreads();
     const int n = n_in;
+    // bitonic sort, one compare-exchange per thread and pass over m / 2 pairs
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < m; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = keys[i], b = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-                }
+            for (int t = tid; t < (m >> 1); t += FVB_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // the pair's lower index: bit j clear
+                const int l = i | j;
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
             }
             __syncthreads();
         }
     uint32_t *fv_node = const_cast<uint32_t *>(F.fv_node), *fv_off = const_cast<uint32_t *>(F.fv_off), *fv_idx = const_cast<uint32_t *>(F.fv_idx);
-    // run heads: thread t owns positions [t*per, (t+1)*per)
-    const int per = (n + 255) / 256;
-    const int p0 = tid * per, p1 = min(n, p0 + per);
+    // run heads: thread t owns positions [t*per, (t+1)*per); exclusive scan of the head counts over the workgroup
+    const int per = (n + FVB_THREADS - 1) / FVB_THREADS;
+    const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
     uint32_t heads = 0;
     for (int p = p0; p < p1; p++) heads += (p == 0 || (keys[p] >> 32) != (keys[p - 1] >> 32)) ? 1u : 0u;
     part[tid] = heads;
     __syncthreads();
-    uint32_t base = 0;
-    for (int t = 0; t < tid; t++) base += part[t];
-    uint32_t total = base;
-    for (int t = tid; t < 256; t++) total += part[t];
+    for (int d = 1; d < FVB_THREADS; d <<= 1) {
+        const uint32_t add = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t base = part[tid] - heads;
+    const uint32_t total = part[FVB_THREADS - 1];
     for (int p = p0; p < p1; p++) {
         const unsigned long long kp = keys[p];
         fv_idx[p] = (uint32_t)kp;
@@ -121,6 +207,8 @@ __global__ __launch_bounds__(256) void fv_build_kernel(FrameDev *__restrict__ ta
 }
 
 }  // namespace
+
+extern "C" void orbm__vocab_variant(int v) { g_vocab_variant = v; }
 
 extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_t *vocab_id) {
     if (!ctx) return ORBM_EINVAL;
@@ -141,14 +229,23 @@ extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_
         }
         if (v->child_off[i + 1] == v->child_off[i] && v->word_id[i] < 0)
             return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: leaf %zu has no word id", i);
+        if (v->child_off[i + 1] - v->child_off[i] > (uint32_t)VOC_MAX_CHILDREN)
+            return orbm_fail(ctx, ORBM_ELIMIT, "vocab_upload: node %zu has more than %d children", i, VOC_MAX_CHILDREN);
+    }
+    std::vector<uint2> rec(nn);
+    for (size_t i = 0; i < nn; i++) {
+        const uint32_t b = v->child_off[i], cnt = v->child_off[i + 1] - b;
+        bool contiguous = cnt > 0;
+        for (uint32_t c = 1; c < cnt && contiguous; c++) contiguous = v->child_idx[b + c] == v->child_idx[b] + c;
+        rec[i] = contiguous ? make_uint2(v->child_idx[b], cnt | 0x80000000u) : make_uint2(b, cnt);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t o_off = 0, o_idx = (nn + 1) * 4, o_desc = ((o_idx + (size_t)nchild * 4 + 255) / 256) * 256;
+    const size_t o_off = 0, o_idx = nn * 8, o_desc = ((o_idx + (size_t)nchild * 4 + 255) / 256) * 256;
     const size_t o_word = o_desc + nn * 32, total = o_word + nn * 4;
     VocabDev V;
     { int rc = orbm_arena_alloc(ctx, total, &V.arena); if (rc) return rc; }
     char *b = (char *)V.arena.base;
-    HIPCHK(ctx, hipMemcpy(b + o_off, v->child_off, (nn + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b + o_off, rec.data(), nn * 8, hipMemcpyHostToDevice));
     if (nchild) HIPCHK(ctx, hipMemcpy(b + o_idx, v->child_idx, (size_t)nchild * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(b + o_desc, v->desc, nn * 32, hipMemcpyHostToDevice));
     std::vector<int32_t> words(v->word_id, v->word_id + nn);
@@ -158,7 +255,7 @@ extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_
     }
     HIPCHK(ctx, hipMemcpy(b + o_word, words.data(), nn * 4, hipMemcpyHostToDevice));
     V.n_nodes = v->n_nodes; V.depth = v->depth;
-    V.child_off = (const uint32_t *)(b + o_off); V.child_idx = (const uint32_t *)(b + o_idx);
+    V.node_rec = (const uint2 *)(b + o_off); V.child_idx = (const uint32_t *)(b + o_idx);
     V.desc = (const uint32_t *)(b + o_desc); V.word_id = (const int32_t *)(b + o_word);
     int id = -1;
     for (size_t i = 0; i < ctx->vocabs.size(); i++) if (!ctx->vocabs[i].arena.base) { id = (int)i; break; }
@@ -212,17 +309,22 @@ extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_fr
     HIPCHK(ctx, hipMemsetAsync(dn, 0xFF, elems * 4, ctx->stream));
     const VocabDev &V = ctx->vocabs[vocab_id];
     if (max_n > 0) {
-        const int bpf = (max_n + 255) / 256;
-        hipLaunchKernelGGL(transform_kernel, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
-                           (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
+        const int nf = descents_per_group((size_t)n_frames * max_n);
+        const int per_block = 256 / VOC_GROUP * nf, bpf = (max_n + per_block - 1) / per_block;
+        if (nf == 4)
+            hipLaunchKernelGGL(transform_kernel<4>, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
+                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
+        else
+            hipLaunchKernelGGL(transform_kernel<1>, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
+                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
         HIPCHK(ctx, hipGetLastError());
     }
     int m = 1;
     while (m < max_n) m <<= 1;
-    const size_t lds = (size_t)m * 8;
+    const size_t lds = (size_t)std::max(m, 2) * 8;
     if (lds > 48 * 1024)
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fv_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fv_build_kernel, dim3(n_frames), dim3(256), lds, ctx->stream, ctx->d_frames, (const int32_t *)dids, st,
+    hipLaunchKernelGGL(fv_build_kernel, dim3(n_frames), dim3(FVB_THREADS), lds, ctx->stream, ctx->d_frames, (const int32_t *)dids, st,
                        (const int32_t *)dn, (int32_t *)dnn);
     HIPCHK(ctx, hipGetLastError());
     rc = io.finish();
@@ -266,8 +368,14 @@ extern "C" int orbm_vocab_transform(orbm_ctx *ctx, int32_t vocab_id, int n, cons
     const void *dd; void *dw, *dn;
     if ((rc = io.in(desc, (size_t)n * 32, &dd)) || (rc = io.out(word_id, (size_t)n * 4, &dw)) || (rc = io.out(node_id, (size_t)n * 4, &dn)))
         return rc;
-    hipLaunchKernelGGL(transform_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)dd, n,
-                       ctx->vocabs[vocab_id], levelsup, (int32_t *)dw, (int32_t *)dn);
+    const int nf = descents_per_group((size_t)n);
+    const int per_block = 256 / VOC_GROUP * nf;
+    if (nf == 4)
+        hipLaunchKernelGGL(transform_flat_kernel<4>, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, ctx->stream, (const uint32_t *)dd, n,
+                           ctx->vocabs[vocab_id], levelsup, (int32_t *)dw, (int32_t *)dn);
+    else
+        hipLaunchKernelGGL(transform_flat_kernel<1>, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, ctx->stream, (const uint32_t *)dd, n,
+                           ctx->vocabs[vocab_id], levelsup, (int32_t *)dw, (int32_t *)dn);
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }

@@ -332,3 +332,32 @@ def vocabulary_features(rng, vocab, n, flip=0.1):
     noisy = bits ^ (rng.random(bits.shape) < flip).astype(np.uint8)
     noisy[: n // 8] = bits[: n // 8]
     return np.packbits(noisy, axis=1)
+
+
+def make_vocabulary_regular(seed=SEED0 + 10, k=10, depth=6):
+    """Full k-ary tree of the given depth (ORBvoc.txt is k = 10, depth = 6: 1 111 111 nodes, 10^6 words), breadth-first ids,
+    built level by level with array operations: a child = its parent with about 1/8 of the bits flipped (1/4 below the
+    root's children)."""
+    from .views import VocabData
+    rng = np.random.default_rng(seed)
+    levels = [np.zeros((1, 32), np.uint8)]
+    for lv in range(1, depth + 1):
+        parent = np.repeat(levels[-1], k, axis=0)
+        m = parent.shape[0]
+        if lv == 1:
+            child = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        else:
+            flips = rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8)
+            if lv > 2:
+                flips &= rng.integers(0, 256, (m, 32), dtype=np.uint8)
+            child = parent ^ flips
+        levels.append(child)
+    desc = np.concatenate(levels)
+    n_nodes = desc.shape[0]
+    n_inner = n_nodes - levels[-1].shape[0]
+    child_off = np.minimum(np.arange(n_nodes + 1, dtype=np.int64), n_inner) * k
+    child_idx = np.arange(1, n_nodes, dtype=np.uint32)
+    word_id = np.full(n_nodes, -1, np.int32)
+    word_id[n_inner:] = np.arange(n_nodes - n_inner)
+    return VocabData(depth=depth, child_off=child_off.astype(np.uint32), child_idx=child_idx, desc=desc, word_id=word_id,
+                     weight=rng.random(n_nodes) * 5 + 0.01)

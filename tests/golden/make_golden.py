@@ -72,6 +72,28 @@ def make_next_rows():
     si, sd, _ = orc.stereo_match(left, right, 480, 45.0)
     d.update(stereo_idx=si, stereo_dist=sd, stereo_max_d=np.float32(45.0))
     np.savez_compressed(os.path.join(OUT, "next_rows.npz"), **d)
+    make_vocab()
+
+
+VOCAB_KEYS = ["child_off", "child_idx", "desc", "word_id", "weight"]
+
+
+def unpack_vocab(z):
+    from orbslam2_amd.views import VocabData
+    return VocabData(depth=int(z["voc_depth"]), **{k: z[f"voc_{k}"] for k in VOCAB_KEYS})
+
+
+def make_vocab():
+    """An irregular tree with sibling ties and stopped words, 600 features, the restated DBoW2 descent at two levelsup."""
+    vocab = synth.make_vocabulary(seed=41, k=5, depth=4, irregular=True, tie_frac=0.2, stop_frac=0.15)
+    rng = np.random.default_rng(42)
+    feat = synth.vocabulary_features(rng, vocab, 600)
+    d = {f"voc_{k}": getattr(vocab, k) for k in VOCAB_KEYS}
+    d.update(voc_depth=np.int32(vocab.depth), feat=feat)
+    for up in (1, 4):
+        w, n, (fn, fo, fi) = orc.transform(vocab, feat, up)
+        d.update({f"t{up}_word": w, f"t{up}_node": n, f"t{up}_fv_node": fn, f"t{up}_fv_off": fo, f"t{up}_fv_idx": fi})
+    np.savez_compressed(os.path.join(OUT, "vocab_transform.npz"), **d)
 
 
 def main():

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
 mg = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mg)
+from orbslam2_amd import synth  # noqa: E402
 from orbslam2_amd.views import ProjQueries, WinQueries  # noqa: E402
 
 
@@ -35,6 +36,7 @@ class OracleSide:
     def free(self, f, q, dth, chi2): return self.orc.search_window_free(f, q, dth, chi2)[0]
     def distinct(self, off, desc): return np.array([self.orc.distinctive_descriptor(desc[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
     def stereo(self, l, r, md): i, d, _ = self.orc.stereo_match(l, r, 480, md); return i, d
+    def transform(self, vocab, feat, up): w, n, fv = self.orc.transform(vocab, feat, up); return (w, n) + tuple(fv)
 
 
 class GpuSide:
@@ -83,6 +85,16 @@ class GpuSide:
         return i[0], d[0]
 
 
+    def transform(self, vocab, feat, up):
+        rng = np.random.default_rng(0)
+        ids = self._up(synth.make_frame(rng, feat, np.arange(len(feat)), p_flip=0.0, with_fv=False))
+        vid = self.ctx.upload_vocabulary(vocab)
+        w, n = self.ctx.compute_bow(vid, ids, up, stride=len(feat))
+        fv = self.ctx.feature_vector(ids[0], len(feat))
+        self.ctx.free_vocabulary(vid); self.ctx.free_frames(ids)
+        return (w[0], n[0]) + tuple(fv)
+
+
 def check_all(side):
     z = load("pair_bf_bow.npz")
     a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
@@ -124,6 +136,14 @@ def check_all(side):
     l, r = mg.unpack_frame(z, "sl"), mg.unpack_frame(z, "sr")
     i, d = side.stereo(l, r, float(z["stereo_max_d"]))
     assert np.array_equal(i, z["stereo_idx"]) and np.array_equal(d, z["stereo_dist"]) and (z["stereo_dist"] < 75).sum() > 100
+
+    z = load("vocab_transform.npz")
+    vocab = mg.unpack_vocab(z)
+    for up in (1, 4):
+        got = side.transform(vocab, z["feat"], up)
+        for g, key in zip(got, ("word", "node", "fv_node", "fv_off", "fv_idx")):
+            assert np.array_equal(g, z[f"t{up}_{key}"]), (up, key)
+    assert (z["t1_node"] < 0).sum() > 20 and len(z["t1_fv_node"]) > 10 and z["t4_fv_node"].tolist() == [0]
 
 
 def test_oracle_reproduces_golden(orc):

@@ -590,11 +590,14 @@ def _vocab_cases():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", [1, 4])
 @pytest.mark.parametrize("case", range(5))
-def test_vocabulary_transform_parity(ctx, orc, case):
+def test_vocabulary_transform_parity(ctx, orc, case, form):
     """DBoW2 transform on the device (Frame::ComputeBoW / KeyFrame::ComputeBoW): word ids, node ids and the FeatureVector
     left in the frame, against the restated DBoW2 descent; regular and irregular trees, exact ties between siblings,
-    stopped words, levelsup from the leaves to above the root, empty frames, frames of different sizes in one call."""
+    stopped words, levelsup from the leaves to above the root, empty frames, frames of different sizes in one call; both
+    kernel forms (1 and 4 descents per lane group; the library picks by size)."""
+    from orbslam2_amd import _lib
     kw = _vocab_cases()[case]
     vocab = synth.make_vocabulary(seed=500 + case, **kw)
     rng = np.random.default_rng(900 + case)
@@ -605,6 +608,7 @@ def test_vocabulary_transform_parity(ctx, orc, case):
         frames.append(synth.make_frame(rng, d, np.arange(n), p_flip=0.0, with_fv=(n == 257)))   # one arrives with a host FV
     ids = ctx.upload_frames(frames)
     vid = ctx.upload_vocabulary(vocab)
+    _lib.load().orbm__vocab_variant(form)
     try:
         for levelsup in ([4, 0, 1, 2, vocab.depth, vocab.depth + 3] if case < 3 else [4, 1]):
             word, node = ctx.compute_bow(vid, ids, levelsup, stride=max(sizes))
@@ -624,6 +628,7 @@ def test_vocabulary_transform_parity(ctx, orc, case):
         gn, go, gi = ctx.feature_vector(ids[0], frames[0].n)
         assert np.array_equal(gn, fn) and np.array_equal(go, fo) and np.array_equal(gi, fi)
     finally:
+        _lib.load().orbm__vocab_variant(0)
         ctx.free_vocabulary(vid)
         ctx.free_frames(ids)
 
