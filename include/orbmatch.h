@@ -143,6 +143,22 @@ int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
 int orbm_hamming256_pairs(orbm_ctx *ctx, int n, const uint8_t *a, const uint8_t *b, int32_t *dist,
                           int io_on_device);
 
+/* ---- the scoring inside KeyFrameDatabase::DetectLoopCandidates / DetectRelocalizationCandidates
+ * (KeyFrameDataBase.cc:109-285, 287-431): `mpVoc->score(query.mBowVec, pKFi->mBowVec)` (:188, :356) for many keyframes per
+ * call, and the number of shared words (mnLoopWords / mnRelocWords).  DBoW2's L1Scoring (ORBvoc.txt's scoring type).
+ * A BowVector arrives flat: n ascending word ids and their values (DBoW2::BowVector is a std::map<WordId, double>). */
+typedef struct orbm_bowvec_view {
+    int32_t n;                   /* at most 16384 words */
+    const uint32_t *word;        /* strictly ascending */
+    const double *value;
+} orbm_bowvec_view;
+int orbm_bowvecs_upload(orbm_ctx *ctx, int n_vecs, const orbm_bowvec_view *views, int32_t *out_ids);
+int orbm_bowvecs_free(orbm_ctx *ctx, int n_vecs, const int32_t *ids);
+/* score[p] = L1Scoring::score(vec_a[p], vec_b[p]) (double; the reference narrows it to float), common[p] (nullable) = number
+ * of words both hold.  With io_on_device the id lists and outputs are device addresses and the ids are not checked. */
+int orbm_bow_score_batch(orbm_ctx *ctx, int n_pairs, const int32_t *vec_a, const int32_t *vec_b, double *score,
+                         int32_t *common, int io_on_device);
+
 /* ---- DBoW2 TemplatedVocabulary::transform(features, ..., FeatureVector, levelsup), word / node part,
  * as called by Frame::ComputeBoW (Frame.cc:526-533) and KeyFrame::ComputeBoW (KeyFrame.cc:69-78) with levelsup = 4.
  * DBoW2 is not part of the reference tree; the tree arrives flat.  Node 0 is the root; the children of node i are

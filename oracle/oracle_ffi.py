@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from orbslam2_amd.views import CFrameView, CProjQueries, CVocabView, CWinQueries, GRID_CELLS
+from orbslam2_amd.views import CBowVecView, CFrameView, CProjQueries, CVocabView, CWinQueries, GRID_CELLS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liborb_oracle.so")
@@ -51,6 +51,8 @@ def lib():
         L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
         L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
         L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p]
+        L.orc_bow_score.argtypes = [C.POINTER(CBowVecView), C.POINTER(CBowVecView), i32p]
+        L.orc_bow_score.restype = C.c_double
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
         _lib = L
     return _lib
@@ -198,3 +200,11 @@ def transform(vocab, desc, levelsup: int):
     nn = lib().orc_transform(C.byref(v), _p(d, C.c_uint8) if n else None, n, levelsup, _p(word, C.c_int32), _p(node, C.c_int32),
                              _p(fv_node, C.c_uint32), _p(fv_off, C.c_uint32), _p(fv_idx, C.c_uint32))
     return word[:n], node[:n], (fv_node[:nn].copy(), fv_off[:nn + 1].copy(), fv_idx[:int(fv_off[nn])].copy())
+
+
+def bow_score(a, b):
+    """-> (L1 score as DBoW2 computes it, number of common words)"""
+    va, vb = a.view(), b.view()
+    common = C.c_int32(0)
+    s = lib().orc_bow_score(C.byref(va), C.byref(vb), C.byref(common))
+    return float(s), int(common.value)

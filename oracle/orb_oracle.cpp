@@ -20,6 +20,7 @@
 #include <string.h>
 #include <limits.h>
 #include <map>
+#include <set>
 #include <vector>
 #include <algorithm>
 
@@ -756,6 +757,126 @@ int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int leve
     }
     fv_off[j] = pos;
     return j;
+}
+
+// DBoW2 L1Scoring::score(v1, v2) on std::map BowVectors (third-party, absent from the reference tree; parity unpinned):
+// the walk with lower_bound jumps, the double sum in ascending word order, -score / 2.  Also counts the common words.
+static double l1_score_maps(const std::map<uint32_t, double> &v1, const std::map<uint32_t, double> &v2, int *common) {
+    auto v1_it = v1.begin(), v2_it = v2.begin();
+    const auto v1_end = v1.end(), v2_end = v2.end();
+    double score = 0;
+    int n = 0;
+    while (v1_it != v1_end && v2_it != v2_end) {
+        const double &vi = v1_it->second;
+        const double &wi = v2_it->second;
+        if (v1_it->first == v2_it->first) {
+            score += fabs(vi - wi) - fabs(vi) - fabs(wi);
+            n++;
+            ++v1_it;
+            ++v2_it;
+        } else if (v1_it->first < v2_it->first) {
+            v1_it = v1.lower_bound(v2_it->first);
+        } else {
+            v2_it = v2.lower_bound(v1_it->first);
+        }
+    }
+    if (common) *common = n;
+    score = -score / 2.0;
+    return score;
+}
+
+static std::map<uint32_t, double> to_map(const orbm_bowvec_view *v) {
+    std::map<uint32_t, double> m;
+    for (int i = 0; i < v->n; i++) m[v->word[i]] = v->value[i];
+    return m;
+}
+
+double orc_bow_score(const orbm_bowvec_view *a, const orbm_bowvec_view *b, int32_t *common) {
+    int n = 0;
+    const double s = l1_score_maps(to_map(a), to_map(b), &n);
+    if (common) *common = n;
+    return s;
+}
+
+// KeyFrameDatabase::DetectLoopCandidates (KeyFrameDataBase.cc:109-285; is_reloc = 0) and DetectRelocalizationCandidates
+// (:287-431; is_reloc = 1) on keyframe INDICES.  db holds, per keyframe, its BowVector, its mnId, its ten best covisible
+// keyframes in order (GetBestCovisibilityKeyFrames(10)) and the persistent bookkeeping fields the reference keeps in
+// KeyFrame (query id, word counter, last score); inv_* is the inverted file in list order.  connected[k] != 0: keyframe
+// k is in the query's GetConnectedKeyFrames() (loop only).  Returns the number of candidates written to out.
+struct orc_kfdb {
+    int32_t n_kf, n_words;
+    const orbm_bowvec_view *bow;
+    const int64_t *mn_id;
+    const int32_t *nb_off, *nb_idx;
+    const int32_t *inv_off, *inv_idx;
+    int64_t *query;      // mnLoopQuery / mnRelocQuery
+    int32_t *words;      // mnLoopWords / mnRelocWords
+    float *score;        // mLoopScore / mRelocScore
+};
+
+int orc_detect_candidates(int is_reloc, const orc_kfdb *db, const orbm_bowvec_view *q_bow, int64_t q_id, const uint8_t *connected,
+                          float minScore, int32_t *out) {
+    std::vector<int> lKFsSharingWords;                                       // :125-146 / :305-325
+    for (int w = 0; w < q_bow->n; w++) {
+        const uint32_t word = q_bow->word[w];
+        for (int32_t j = db->inv_off[word]; j < db->inv_off[word + 1]; j++) {
+            const int k = db->inv_idx[j];
+            if (db->query[k] != q_id) {
+                db->words[k] = 0;
+                if (is_reloc || !connected[k]) {
+                    db->query[k] = q_id;
+                    lKFsSharingWords.push_back(k);
+                }
+            }
+            db->words[k]++;
+        }
+    }
+    if (lKFsSharingWords.empty()) return 0;
+    int maxCommonWords = 0;                                                  // :160-170 / :332-338
+    for (int k : lKFsSharingWords)
+        if (db->words[k] > maxCommonWords) maxCommonWords = db->words[k];
+    int minCommonWords = maxCommonWords * 0.8f;
+    const std::map<uint32_t, double> qmap = to_map(q_bow);
+    std::vector<std::pair<float, int>> lScoreAndMatch;                       // :179-196 / :347-361
+    for (int k : lKFsSharingWords)
+        if (db->words[k] > minCommonWords) {
+            float si = (float)l1_score_maps(qmap, to_map(&db->bow[k]), nullptr);
+            db->score[k] = si;
+            if (is_reloc || si >= minScore) lScoreAndMatch.push_back(std::make_pair(si, k));
+        }
+    if (lScoreAndMatch.empty()) return 0;
+    std::vector<std::pair<float, int>> lAccScoreAndMatch;                    // :205-232 / :370-400
+    float bestAccScore = is_reloc ? 0.f : minScore;
+    for (auto &sm : lScoreAndMatch) {
+        const int k = sm.second;
+        float bestScore = sm.first;
+        float accScore = sm.first;
+        int best = k;
+        for (int32_t j = db->nb_off[k]; j < db->nb_off[k + 1]; j++) {
+            const int k2 = db->nb_idx[j];
+            if (is_reloc) {
+                if (db->query[k2] != q_id) continue;
+            } else if (!(db->query[k2] == q_id && db->words[k2] > minCommonWords)) {
+                continue;
+            }
+            accScore += db->score[k2];
+            if (db->score[k2] > bestScore) {
+                best = k2;
+                bestScore = db->score[k2];
+            }
+        }
+        lAccScoreAndMatch.push_back(std::make_pair(accScore, best));
+        if (accScore > bestAccScore) bestAccScore = accScore;
+    }
+    float minScoreToRetain = 0.75f * bestAccScore;                           // :241-262 / :403-431
+    std::set<int> already;
+    int n_out = 0;
+    for (auto &am : lAccScoreAndMatch)
+        if (am.first > minScoreToRetain && !already.count(am.second)) {
+            out[n_out++] = am.second;
+            already.insert(am.second);
+        }
+    return n_out;
 }
 
 // MapPoint.cc:569-602 (PredictScale) in flat form: host-side helper of the a11 gates.  MapPoint.cc sees

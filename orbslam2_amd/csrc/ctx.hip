@@ -379,6 +379,8 @@ void orbm_destroy(orbm_ctx *ctx) {
     for (auto &a : ctx->arenas) if (a.base) (void)hipFree(a.base);
     for (auto &a : ctx->arena_pool) if (a.base) (void)hipFree(a.base);
     for (auto &v : ctx->vocabs) if (v.arena.base) (void)hipFree(v.arena.base);
+    for (auto &a : ctx->bvec_arenas) if (a.base) (void)hipFree(a.base);
+    if (ctx->d_bvecs) (void)hipFree(ctx->d_bvecs);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_qsets) (void)hipFree(ctx->d_qsets);
     if (ctx->ws) (void)hipFree(ctx->ws);

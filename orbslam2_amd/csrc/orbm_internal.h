@@ -60,6 +60,13 @@ struct VocabDev {
     Arena arena;
 };
 
+// Device-resident DBoW2::BowVector: ascending word ids and their values
+struct BowVecDev {
+    int32_t n;
+    const uint32_t *word;
+    const double *value;
+};
+
 struct orbm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -80,6 +87,13 @@ struct orbm_ctx {
     size_t d_qsets_cap = 0;
     std::vector<Arena> arenas;
     std::vector<VocabDev> vocabs;      // slot free when arena.base == nullptr
+    // BowVector table (bowscore.hip): one arena per upload batch
+    std::vector<BowVecDev> h_bvecs;
+    std::vector<int> bvec_arena;       // index into bvec_arenas, -1 = free slot
+    std::vector<int32_t> free_bvecs;
+    std::vector<Arena> bvec_arenas;
+    BowVecDev *d_bvecs = nullptr;
+    size_t d_bvecs_cap = 0;
     // released arenas kept for reuse: per-call uploads of the drop-in class (a frame, a query set) would otherwise
     // pay a hipMalloc + hipFree each; bounded in count and bytes
     std::vector<Arena> arena_pool;

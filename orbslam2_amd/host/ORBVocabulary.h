@@ -15,26 +15,6 @@
 
 #include "orbslam_types.h"
 
-namespace DBoW2 {
-
-typedef unsigned int WordId;
-typedef double WordValue;
-typedef unsigned int NodeId;
-
-enum LNorm { L1, L2 };
-enum WeightingType { TF_IDF, TF, IDF, BINARY };
-enum ScoringType { L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT };
-
-// BowVector.h of DBoW2: word id -> value
-class BowVector : public std::map<WordId, WordValue> {
-public:
-    void addWeight(WordId id, WordValue v);
-    void addIfNotExist(WordId id, WordValue v);
-    void normalize(LNorm norm_type);
-};
-
-}  // namespace DBoW2
-
 namespace ORB_SLAM2 {
 
 class ORBVocabulary {

@@ -14,6 +14,22 @@
 namespace DBoW2 {
 // FeatureVector.h of DBoW2: node id -> indices of the local features in that node
 class FeatureVector : public std::map<unsigned int, std::vector<unsigned int>> {};
+
+typedef unsigned int WordId;
+typedef double WordValue;
+typedef unsigned int NodeId;
+
+enum LNorm { L1, L2 };
+enum WeightingType { TF_IDF, TF, IDF, BINARY };
+enum ScoringType { L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT };
+
+// BowVector.h of DBoW2: word id -> value (methods in ORBVocabulary.cc)
+class BowVector : public std::map<WordId, WordValue> {
+public:
+    void addWeight(WordId id, WordValue v);
+    void addIfNotExist(WordId id, WordValue v);
+    void normalize(LNorm norm_type);
+};
 }  // namespace DBoW2
 
 #define FRAME_GRID_ROWS 48
@@ -72,6 +88,8 @@ public:
 
 class Frame {
 public:
+    long unsigned int mnId = 0;
+    DBoW2::BowVector mBowVec;
     int N = 0;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
@@ -93,6 +111,21 @@ public:
 class KeyFrame {
 public:
     long unsigned int mnId = 0;
+    DBoW2::BowVector mBowVec;
+    // KeyFrameDatabase bookkeeping (KeyFrame.h:152-160)
+    long unsigned int mnLoopQuery = 0;
+    int mnLoopWords = 0;
+    float mLoopScore = 0;
+    long unsigned int mnRelocQuery = 0;
+    int mnRelocWords = 0;
+    float mRelocScore = 0;
+    // covisibility graph as the database reads it (KeyFrame.cc:193-236): the stand-in stores the ordered list directly
+    std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames;
+    std::set<KeyFrame *> GetConnectedKeyFrames() { return std::set<KeyFrame *>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.end()); }
+    std::vector<KeyFrame *> GetBestCovisibilityKeyFrames(const int &N_) {
+        if ((int)mvpOrderedConnectedKeyFrames.size() < N_) return mvpOrderedConnectedKeyFrames;
+        return std::vector<KeyFrame *>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + N_);
+    }
     int N = 0;
     std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;

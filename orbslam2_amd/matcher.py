@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .views import CFrameView, CProjQueries, CWinQueries, FrameData, ProjQueries, WinQueries, GRID_CELLS
+from .views import CBowVecView, CFrameView, CProjQueries, CWinQueries, FrameData, ProjQueries, WinQueries, GRID_CELLS
 
 
 class OrbmError(RuntimeError):
@@ -162,6 +162,32 @@ class Context:
         self._chk(self._L.orbm_frame_fv_download(self._h, int(fid), C.byref(nn), _addr(fv_node), _addr(fv_off), _addr(fv_idx)))
         k = int(nn.value)
         return fv_node[:k], fv_off[:k + 1], fv_idx[: int(fv_off[k])]
+
+    # ---- KeyFrameDatabase scoring (DBoW2 L1 score between BowVectors) ----
+    def upload_bowvecs(self, vecs) -> np.ndarray:
+        n = len(vecs)
+        arr = (CBowVecView * max(n, 1))()
+        keep = [v.view() for v in vecs]
+        for i, v in enumerate(keep):
+            arr[i] = v
+        ids = np.zeros(max(n, 1), np.int32)
+        self._chk(self._L.orbm_bowvecs_upload(self._h, n, arr, _addr(ids)))
+        return ids[:n]
+
+    def free_bowvecs(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._chk(self._L.orbm_bowvecs_free(self._h, len(ids), _addr(ids)))
+
+    def bow_score(self, va, vb):
+        va = np.ascontiguousarray(va, np.int32); vb = np.ascontiguousarray(vb, np.int32)
+        p = len(va)
+        score = np.zeros(max(p, 1), np.float64)
+        common = np.zeros(max(p, 1), np.int32)
+        self._chk(self._L.orbm_bow_score_batch(self._h, p, _addr(va), _addr(vb), _addr(score), _addr(common), 0))
+        return score[:p], common[:p]
+
+    def bow_score_dev(self, n_pairs, va_ptr, vb_ptr, score_ptr, common_ptr):
+        self._chk(self._L.orbm_bow_score_batch(self._h, n_pairs, va_ptr, vb_ptr, score_ptr, common_ptr, 1))
 
     # ---- a1 ----
     def hamming_pairs(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:

@@ -361,3 +361,29 @@ def make_vocabulary_regular(seed=SEED0 + 10, k=10, depth=6):
     word_id[n_inner:] = np.arange(n_nodes - n_inner)
     return VocabData(depth=depth, child_off=child_off.astype(np.uint32), child_idx=child_idx, desc=desc, word_id=word_id,
                      weight=rng.random(n_nodes) * 5 + 0.01)
+
+
+def bow_vectors(seed=SEED0 + 11, n_vec=64, n_words_vocab=100000, n_feat=2000, shared=0.4, group=8):
+    """BowVectors as ComputeBoW leaves them (TF-IDF weights summed per word, L1-normalised in word order): vectors of one
+    group (consecutive keyframes seeing the same place) draw `shared` of their words from a common pool."""
+    from .views import BowVecData
+    rng = np.random.default_rng(seed)
+    idf = rng.random(n_words_vocab) * 8 + 0.05
+    out = []
+    pool = None
+    for k in range(n_vec):
+        if k % group == 0:
+            pool = rng.integers(0, n_words_vocab, n_feat)
+        words = np.where(rng.random(n_feat) < shared, pool[rng.integers(0, n_feat, n_feat)], rng.integers(0, n_words_vocab, n_feat))
+        uniq, cnt = np.unique(words, return_counts=True)
+        val = np.zeros(len(uniq))
+        for i, (w, c) in enumerate(zip(uniq, cnt)):      # addWeight: one add per feature
+            acc = 0.0
+            for _ in range(int(c)):
+                acc += idf[w]
+            val[i] = acc
+        norm = 0.0
+        for v in val:
+            norm += abs(v)
+        out.append(BowVecData(word=uniq.astype(np.uint32), value=val / norm))
+    return out

@@ -89,6 +89,10 @@ class CVocabView(C.Structure):
     ]
 
 
+class CBowVecView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("word", _u32p), ("value", C.POINTER(C.c_double))]
+
+
 def _ptr(a: Optional[np.ndarray], ctype):
     if a is None:
         return C.cast(None, C.POINTER(ctype))
@@ -271,5 +275,26 @@ class VocabData:
         v = CVocabView(n_nodes=self.n_nodes, depth=int(self.depth), child_off=_ptr(self.child_off, C.c_uint32),
                        child_idx=_ptr(self.child_idx, C.c_uint32), desc=_ptr(self.desc, C.c_uint8),
                        word_id=_ptr(self.word_id, C.c_int32), weight=_ptr(self.weight, C.c_double))
+        v._owner = self
+        return v
+
+
+@dataclass
+class BowVecData:
+    """Flat DBoW2::BowVector (orbm_bowvec_view): ascending word ids and their values."""
+    word: np.ndarray    # [n] uint32
+    value: np.ndarray   # [n] float64
+
+    def __post_init__(self):
+        self.word = _as(self.word, np.uint32)
+        self.value = _as(self.value, np.float64)
+        assert self.word.shape == self.value.shape
+
+    @property
+    def n(self) -> int:
+        return int(self.word.shape[0])
+
+    def view(self) -> CBowVecView:
+        v = CBowVecView(n=self.n, word=_ptr(self.word, C.c_uint32), value=_ptr(self.value, C.c_double))
         v._owner = self
         return v

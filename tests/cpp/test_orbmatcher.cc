@@ -2,11 +2,13 @@
 // oracle.  The test generates flat arrays first, hands them to the oracle (orc_* in oracle/orb_oracle.cpp),
 // then builds the pointer graph (Frame / KeyFrame / MapPoint objects) from the same arrays, calls the class
 // (which runs on the GPU) and compares pointers, counts and side effects.  Run by tests/test_gpu_cpp_class.py.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <random>
 #include <set>
@@ -15,6 +17,7 @@
 #include "../../include/orbmatch.h"
 #include "../../orbslam2_amd/host/ORBmatcher.h"
 #include "../../orbslam2_amd/host/ORBVocabulary.h"
+#include "../../orbslam2_amd/host/KeyFrameDatabase.h"
 #include "../../orbslam2_amd/host/host_gates.h"
 
 using namespace ORB_SLAM2;
@@ -29,6 +32,17 @@ int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, 
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize, float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp);
 int orc_distinctive_descriptor(const uint8_t *desc, int n);
 int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx);
+struct orc_kfdb {
+    int32_t n_kf, n_words;
+    const orbm_bowvec_view *bow;
+    const int64_t *mn_id;
+    const int32_t *nb_off, *nb_idx;
+    const int32_t *inv_off, *inv_idx;
+    int64_t *query;
+    int32_t *words;
+    float *score;
+};
+int orc_detect_candidates(int is_reloc, const orc_kfdb *db, const orbm_bowvec_view *q_bow, int64_t q_id, const uint8_t *connected, float minScore, int32_t *out);
 int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels);
 }
 
@@ -757,6 +771,146 @@ static void TestVocabulary() {
     printf("ORBVocabulary done\n");
 }
 
+// KeyFrameDatabase: keyframes whose BowVectors come from ORBVocabulary::transform, add / erase, then an interleaved series
+// of DetectLoopCandidates / DetectRelocalizationCandidates against the oracle's flat restatement (same inverted-file
+// order, same persistent per-keyframe fields): candidate lists in order, and the bookkeeping fields after every query.
+static void TestKeyFrameDatabase() {
+    const int k = 8, L = 3;
+    char path[256];
+    snprintf(path, sizeof path, "/tmp/orbm_test_voc2_%ld.txt", (long)(rng() % 1000000));
+    vector<Desc> of = {Desc()};
+    {
+        std::ofstream f(path);
+        f << k << " " << L << " 0 0\n";
+        f.precision(17);
+        vector<int> frontier = {0};
+        int next_id = 1;
+        for (int lv = 1; lv <= L; lv++) {
+            vector<int> next;
+            for (int p : frontier)
+                for (int c = 0; c < k; c++) {
+                    Desc d = lv == 1 ? RandDesc() : Observe(of[p], 0.2);
+                    f << p << " " << (lv == L ? 1 : 0) << " ";
+                    for (int j = 0; j < 32; j++) f << (int)d.b[j] << " ";
+                    f << U(0.05, 7.0) << "\n";
+                    of.push_back(d); next.push_back(next_id++);
+                }
+            frontier = next;
+        }
+    }
+    ORBVocabulary voc;
+    EXPECT(voc.loadFromTextFile(path), "loadFromTextFile");
+    remove(path);
+    const int first_leaf = 1 + k + k * k, n_leaf = k * k * k;
+    const int NKF = 140, NPLACE = 14;
+    // a "place" = 60 leaves; a keyframe of that place sees 200 features near them plus 60 random ones
+    vector<vector<int>> place(NPLACE);
+    for (auto &pl : place) for (int i = 0; i < 60; i++) pl.push_back(first_leaf + RI(n_leaf));
+    auto bow_of = [&](int pl, DBoW2::BowVector &bv) {
+        vector<cv::Mat> rows;
+        for (int i = 0; i < 260; i++) {
+            const int leaf = i < 200 ? place[pl][RI(60)] : first_leaf + RI(n_leaf);
+            Desc d = Observe(of[leaf], 0.04);
+            cv::Mat m(1, 32, CV_8U); memcpy(m.ptr<uint8_t>(), d.b, 32); rows.push_back(m);
+        }
+        DBoW2::FeatureVector fv;
+        voc.transform(rows, bv, fv, 4);
+    };
+    vector<std::unique_ptr<KeyFrame>> kfs;
+    vector<int> place_of;
+    for (int i = 0; i < NKF; i++) {
+        kfs.emplace_back(new KeyFrame());
+        kfs.back()->mnId = (long unsigned int)i;                  // keyframe 0 has mnId 0, like the reference's first keyframe
+        place_of.push_back(i * NPLACE / NKF < NPLACE / 2 ? i * NPLACE / NKF : RI(NPLACE));   // first half sequential, then revisits
+        bow_of(place_of.back(), kfs.back()->mBowVec);
+    }
+    for (int i = 0; i < NKF; i++) {                                // covisibility lists: up to 14 neighbours, same place first
+        vector<KeyFrame *> nb;
+        for (int j = 0; j < NKF; j++) if (j != i && place_of[j] == place_of[i] && U(0, 1) < 0.7) nb.push_back(kfs[j].get());
+        for (int t = 0; t < 3; t++) { KeyFrame *o = kfs[RI(NKF)].get(); if (o != kfs[i].get() && std::find(nb.begin(), nb.end(), o) == nb.end()) nb.push_back(o); }
+        if (nb.size() > 14) nb.resize(14);
+        kfs[i]->mvpOrderedConnectedKeyFrames = nb;
+    }
+    KeyFrameDatabase db(voc);
+    vector<int> order;                                             // add order; a few are erased again, two re-added
+    for (int i = 0; i < NKF; i++) { db.add(kfs[i].get()); order.push_back(i); }
+    for (int e : {5, 77, 78, 130}) { db.erase(kfs[e].get()); order.erase(std::find(order.begin(), order.end(), e)); }
+    for (int e : {77, 5}) { db.add(kfs[e].get()); order.push_back(e); }
+
+    // the oracle's flat database
+    std::map<KeyFrame *, int> index;
+    for (int i = 0; i < NKF; i++) index[kfs[i].get()] = i;
+    vector<vector<uint32_t>> words(NKF); vector<vector<double>> vals(NKF);
+    vector<orbm_bowvec_view> bows(NKF);
+    for (int i = 0; i < NKF; i++) {
+        for (auto &kv : kfs[i]->mBowVec) { words[i].push_back(kv.first); vals[i].push_back(kv.second); }
+        bows[i].n = (int)words[i].size(); bows[i].word = words[i].data(); bows[i].value = vals[i].data();
+    }
+    vector<int64_t> mn_id(NKF); for (int i = 0; i < NKF; i++) mn_id[i] = i;
+    vector<int32_t> nb_off = {0}, nb_idx;
+    for (int i = 0; i < NKF; i++) {
+        auto v = kfs[i]->GetBestCovisibilityKeyFrames(10);
+        for (KeyFrame *o : v) nb_idx.push_back(index[o]);
+        nb_off.push_back((int)nb_idx.size());
+    }
+    const int NW = (int)voc.size();
+    vector<vector<int>> inv(NW);
+    for (int i : order) for (auto &kv : kfs[i]->mBowVec) inv[kv.first].push_back(i);
+    vector<int32_t> inv_off = {0}, inv_idx;
+    for (int w = 0; w < NW; w++) { for (int i : inv[w]) inv_idx.push_back(i); inv_off.push_back((int)inv_idx.size()); }
+    vector<int64_t> lq(NKF, 0), rq(NKF, 0); vector<int32_t> lw(NKF, 0), rw(NKF, 0); vector<float> ls(NKF, 0), rs(NKF, 0);
+    orc_kfdb odb;
+    odb.n_kf = NKF; odb.n_words = NW; odb.bow = bows.data(); odb.mn_id = mn_id.data(); odb.nb_off = nb_off.data(); odb.nb_idx = nb_idx.data();
+    odb.inv_off = inv_off.data(); odb.inv_idx = inv_idx.data();
+
+    int total_loop = 0, total_reloc = 0, bad_lists = 0, bad_fields = 0;
+    double t_loop = 0, t_reloc = 0;
+    vector<int32_t> out(NKF);
+    for (int it = 0; it < 60; it++) {
+        if (it % 2 == 0) {                                         // loop query from a keyframe of the database
+            const int q = it == 0 ? 0 : (it == 2 ? 139 : RI(NKF));
+            vector<uint8_t> connected(NKF, 0);
+            for (KeyFrame *o : kfs[q]->GetConnectedKeyFrames()) connected[index[o]] = 1;
+            const float minScore = it % 4 == 0 ? 0.02f : 0.1f;
+            odb.query = lq.data(); odb.words = lw.data(); odb.score = ls.data();
+            const int nwant = orc_detect_candidates(0, &odb, &bows[q], q, connected.data(), minScore, out.data());
+            double t0 = NowMs();
+            vector<KeyFrame *> got = db.DetectLoopCandidates(kfs[q].get(), minScore);
+            t_loop += NowMs() - t0;
+            bool same = (int)got.size() == nwant;
+            for (int i = 0; same && i < nwant; i++) same = index[got[i]] == out[i];
+            bad_lists += !same; total_loop += nwant;
+        } else {                                                   // relocalisation query from a new frame of some place
+            Frame F; F.mnId = (long unsigned int)(it / 2);         // frame ids 0, 1, 2, ...
+            bow_of(RI(NPLACE), F.mBowVec);
+            vector<uint32_t> fw; vector<double> fvv;
+            for (auto &kv : F.mBowVec) { fw.push_back(kv.first); fvv.push_back(kv.second); }
+            orbm_bowvec_view fb; fb.n = (int)fw.size(); fb.word = fw.data(); fb.value = fvv.data();
+            odb.query = rq.data(); odb.words = rw.data(); odb.score = rs.data();
+            const int nwant = orc_detect_candidates(1, &odb, &fb, (int64_t)F.mnId, nullptr, 0.f, out.data());
+            double t0 = NowMs();
+            vector<KeyFrame *> got = db.DetectRelocalizationCandidates(&F);
+            t_reloc += NowMs() - t0;
+            bool same = (int)got.size() == nwant;
+            for (int i = 0; same && i < nwant; i++) same = index[got[i]] == out[i];
+            bad_lists += !same; total_reloc += nwant;
+        }
+        for (int i = 0; i < NKF; i++) {
+            KeyFrame &K = *kfs[i];
+            bad_fields += (int64_t)K.mnLoopQuery != lq[i] || K.mnLoopWords != lw[i] || memcmp(&K.mLoopScore, &ls[i], 4) != 0 ||
+                          (int64_t)K.mnRelocQuery != rq[i] || K.mnRelocWords != rw[i] || memcmp(&K.mRelocScore, &rs[i], 4) != 0;
+        }
+    }
+    EXPECT(bad_lists == 0, "KeyFrameDatabase: %d candidate lists differ", bad_lists);
+    EXPECT(bad_fields == 0, "KeyFrameDatabase: %d bookkeeping fields differ", bad_fields);
+    EXPECT(total_loop > 20 && total_reloc > 30, "KeyFrameDatabase: too few candidates (%d loop, %d reloc)", total_loop, total_reloc);
+    db.clear();
+    Frame F; F.mnId = 999; bow_of(0, F.mBowVec);
+    EXPECT(db.DetectRelocalizationCandidates(&F).empty(), "cleared database must return nothing");
+    printf("KeyFrameDatabase done: %d loop + %d reloc candidates over 60 queries; DetectLoopCandidates %.3f ms, DetectRelocalizationCandidates %.3f ms per call (%d keyframes)\n",
+           total_loop, total_reloc, t_loop / 30, t_reloc / 30, NKF);
+}
+
 int main() {
     try {
         // a1 helper
@@ -773,6 +927,7 @@ int main() {
         TestFuse();
         TestDistinctive();
         TestVocabulary();
+        TestKeyFrameDatabase();
     } catch (const std::exception &e) {
         printf("EXCEPTION: %s\n", e.what());
         return 2;

@@ -693,3 +693,33 @@ def test_vocabulary_errors(ctx):
     assert (word >= 0).all() and (node == 0).all()
     ctx.free_vocabulary(vid)
     ctx.free_frames(ids)
+
+
+@pytest.mark.gpu
+def test_bow_score_parity(ctx, orc):
+    """KeyFrameDatabase's similarity: DBoW2 L1 score between BowVectors, every pair of 48 vectors in one call, bit-equal
+    doubles (the sum runs over the common words in ascending order on both sides) and equal common-word counts; empty
+    vectors, a vector against itself, the 16384-word limit."""
+    from orbslam2_amd.matcher import OrbmError
+    from orbslam2_amd.views import BowVecData
+    vecs = synth.bow_vectors(n_vec=46) + [BowVecData([], []), BowVecData([7], [1.0])]
+    ids = ctx.upload_bowvecs(vecs)
+    a, b = np.meshgrid(np.arange(len(vecs)), np.arange(len(vecs)), indexing="ij")
+    a = a.ravel(); b = b.ravel()
+    score, common = ctx.bow_score(ids[a], ids[b])
+    want = [orc.bow_score(vecs[i], vecs[j]) for i, j in zip(a, b)]
+    assert np.array_equal(score.view(np.uint64), np.array([w[0] for w in want], np.float64).view(np.uint64))
+    assert np.array_equal(common, np.array([w[1] for w in want]))
+    assert (common[a != b] > 100).sum() > 200 and np.all(np.abs(score[(a == b) & (a < 46)] - 1.0) < 1e-12)
+    big = BowVecData(np.arange(16384, dtype=np.uint32) * 3, np.full(16384, 1.0 / 16384))
+    bid = ctx.upload_bowvecs([big])
+    s, c = ctx.bow_score([bid[0], ids[0]], [ids[0], bid[0]])
+    assert (s[0], c[0]) == orc.bow_score(big, vecs[0]) and (s[1], c[1]) == orc.bow_score(vecs[0], big)
+    with pytest.raises(OrbmError):
+        ctx.upload_bowvecs([BowVecData(np.arange(16385, dtype=np.uint32), np.ones(16385))])
+    with pytest.raises(OrbmError):
+        ctx.upload_bowvecs([BowVecData([3, 3], [0.5, 0.5])])          # not strictly ascending
+    ctx.free_bowvecs(bid)
+    with pytest.raises(OrbmError):
+        ctx.bow_score([bid[0]], [ids[0]])                             # freed
+    ctx.free_bowvecs(ids)

@@ -250,3 +250,14 @@ def test_vocabulary_transform_known_answers(orc):
     assert fn.tolist() == [1, 2] and fo.tolist() == [0, 2, 3] and fi.tolist() == [1, 4, 3]
     word, node, (fn, fo, fi) = orc.transform(v, np.zeros((0, 32), np.uint8), 1)
     assert len(word) == 0 and len(fn) == 0 and fo.tolist() == [0]
+
+
+def test_bow_l1_score_known_answers(orc):
+    """DBoW2 L1 score by hand: v = {1: .5, 4: .5}, w = {4: .25, 9: .75}: one common word, term |.5-.25| - .5 - .25 = -.5,
+    score = .25; identical vectors -> 1; disjoint -> 0 (as -0.0); empty -> 0."""
+    from orbslam2_amd.views import BowVecData
+    v = BowVecData([1, 4], [0.5, 0.5]); w = BowVecData([4, 9], [0.25, 0.75])
+    assert orc.bow_score(v, w) == (0.25, 1) and orc.bow_score(w, v) == (0.25, 1)
+    assert orc.bow_score(v, v) == (1.0, 2)
+    d = BowVecData([2, 3], [0.5, 0.5]); e = BowVecData([], [])
+    assert orc.bow_score(v, d) == (0.0, 0) and orc.bow_score(v, e) == (0.0, 0) and orc.bow_score(e, e) == (0.0, 0)
