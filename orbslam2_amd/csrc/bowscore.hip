@@ -45,7 +45,8 @@ __global__ __launch_bounds__(64) void bow_score_kernel(const BowVecDev *__restri
         while (mask) {                                     // wave-uniform: the hits' terms in ascending word order
             const int l = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            acc += __shfl(t, l);
+            // l is wave-uniform: two v_readlane_b32 instead of a cross-lane permute through LDS
+            acc += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), l), __builtin_amdgcn_readlane(__double2loint(t), l));
         }
     }
     if (lane == 0) {

@@ -94,6 +94,17 @@ def make_vocab():
         w, n, (fn, fo, fi) = orc.transform(vocab, feat, up)
         d.update({f"t{up}_word": w, f"t{up}_node": n, f"t{up}_fv_node": fn, f"t{up}_fv_off": fo, f"t{up}_fv_idx": fi})
     np.savez_compressed(os.path.join(OUT, "vocab_transform.npz"), **d)
+    # KeyFrameDatabase similarity: 12 BowVectors, every ordered pair, DBoW2 L1 score (double) + common words
+    vecs = synth.bow_vectors(seed=43, n_vec=12, n_words_vocab=5000, n_feat=300, group=4)
+    d = {"n_vec": np.int32(len(vecs))}
+    for i, v in enumerate(vecs):
+        d[f"bv{i}_word"] = v.word; d[f"bv{i}_value"] = v.value
+    sc = np.zeros((12, 12)); cm = np.zeros((12, 12), np.int32)
+    for i in range(12):
+        for j in range(12):
+            sc[i, j], cm[i, j] = orc.bow_score(vecs[i], vecs[j])
+    d.update(score=sc, common=cm)
+    np.savez_compressed(os.path.join(OUT, "bow_score.npz"), **d)
 
 
 def main():

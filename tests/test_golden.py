@@ -37,6 +37,9 @@ class OracleSide:
     def distinct(self, off, desc): return np.array([self.orc.distinctive_descriptor(desc[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
     def stereo(self, l, r, md): i, d, _ = self.orc.stereo_match(l, r, 480, md); return i, d
     def transform(self, vocab, feat, up): w, n, fv = self.orc.transform(vocab, feat, up); return (w, n) + tuple(fv)
+    def bow_scores(self, vecs):
+        r = [[self.orc.bow_score(a, b) for b in vecs] for a in vecs]
+        return np.array([[x[0] for x in row] for row in r]), np.array([[x[1] for x in row] for row in r], np.int32)
 
 
 class GpuSide:
@@ -95,6 +98,14 @@ class GpuSide:
         return (w[0], n[0]) + tuple(fv)
 
 
+    def bow_scores(self, vecs):
+        ids = self.ctx.upload_bowvecs(vecs)
+        a, b = np.meshgrid(np.arange(len(vecs)), np.arange(len(vecs)), indexing="ij")
+        s, c = self.ctx.bow_score(ids[a.ravel()], ids[b.ravel()])
+        self.ctx.free_bowvecs(ids)
+        return s.reshape(a.shape), c.reshape(a.shape)
+
+
 def check_all(side):
     z = load("pair_bf_bow.npz")
     a, b = mg.unpack_frame(z, "a"), mg.unpack_frame(z, "b")
@@ -143,6 +154,12 @@ def check_all(side):
         got = side.transform(vocab, z["feat"], up)
         for g, key in zip(got, ("word", "node", "fv_node", "fv_off", "fv_idx")):
             assert np.array_equal(g, z[f"t{up}_{key}"]), (up, key)
+    z2 = load("bow_score.npz")
+    from orbslam2_amd.views import BowVecData
+    vecs = [BowVecData(z2[f"bv{i}_word"], z2[f"bv{i}_value"]) for i in range(int(z2["n_vec"]))]
+    sc, cm = side.bow_scores(vecs)
+    assert np.array_equal(sc.view(np.uint64), z2["score"].view(np.uint64)) and np.array_equal(cm, z2["common"])
+    assert (z2["common"] > 20).sum() > 30 and (z2["score"] > 0.05).sum() > 30
     assert (z["t1_node"] < 0).sum() > 20 and len(z["t1_fv_node"]) > 10 and z["t4_fv_node"].tolist() == [0]
 
 
