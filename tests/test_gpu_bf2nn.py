@@ -152,3 +152,53 @@ def test_bf2nn_matches_only_path(ctx, orc, ratio, th):
         assert counts[0] == wc
         assert np.array_equal(match[0], wm)
         ctx.free_frames(ids)
+
+
+def test_bf2nn_bench_size_properties(ctx, orc):
+    """The bench's own workload (4096 pairs of 2000 x 2000 from a 96-keyframe store, one launch) through properties that
+    need no oracle at that size, plus the oracle on a sample of the pairs:
+    * batch invariance: the same pairs in four launches, and in reversed order, give the same rows;
+    * a keyframe against itself: every descriptor finds itself at distance 0;
+    * every accepted match satisfies the reference's accept rule on the returned best / second distances, every
+      rejected row violates it; second >= best; match count = number of accepted rows;
+    * the two smallest distances of 200 random (pair, row) samples recomputed on the host with a lookup-table popcount,
+      and the reported match = the first index that reaches the minimum;
+    * 12 sampled pairs bit-equal to the oracle."""
+    kfs = synth.keyframe_pool(seed=2024, n_kf=96, n=2000, window=3000)
+    ids = ctx.upload_frames(kfs)
+    rng = np.random.default_rng(9)
+    P = 4096
+    pa = rng.integers(0, 96, P); pb = rng.integers(0, 96, P)
+    pa[:96] = np.arange(96); pb[:96] = np.arange(96)                    # self pairs
+    counts, match, bd, sd = ctx.bf2nn(ids[pa], ids[pb], 0.75, 50, stride=2000)
+    # batch invariance
+    for lo in range(0, P, 1024):
+        c2, m2, b2, s2 = ctx.bf2nn(ids[pa[lo:lo + 1024]], ids[pb[lo:lo + 1024]], 0.75, 50, stride=2000)
+        assert np.array_equal(c2, counts[lo:lo + 1024]) and np.array_equal(m2, match[lo:lo + 1024])
+        assert np.array_equal(b2, bd[lo:lo + 1024]) and np.array_equal(s2, sd[lo:lo + 1024])
+    c3, m3, _, _ = ctx.bf2nn(ids[pa[::-1]], ids[pb[::-1]], 0.75, 50, stride=2000)
+    assert np.array_equal(c3[::-1], counts) and np.array_equal(m3[::-1], match)
+    # self pairs
+    assert (bd[:96] == 0).all()
+    self_rows = match[:96]
+    ok = self_rows == np.arange(2000)[None, :]
+    assert ok[self_rows >= 0].all() and (self_rows >= 0).mean() > 0.99  # a rejected row = an exact duplicate descriptor in the frame
+    # accept rule on the returned distances: best <= th and (float)best < ratio * (float)second
+    accept = (bd <= 50) & (bd.astype(np.float32) < np.float32(0.75) * sd.astype(np.float32))
+    assert np.array_equal(accept, match >= 0)
+    assert (sd >= bd).all() and np.array_equal(counts, (match >= 0).sum(axis=1))
+    assert ((match >= -1) & (match < 2000)).all()
+    # row minima recomputed on the host for a sample
+    lut = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for _ in range(200):
+        p = int(rng.integers(0, P)); r = int(rng.integers(0, 2000))
+        d = lut[kfs[pa[p]].desc[r][None, :] ^ kfs[pb[p]].desc].sum(axis=1)
+        order = np.argsort(d, kind="stable")
+        assert d[order[0]] == bd[p, r] and d[order[1]] == sd[p, r]
+        if match[p, r] >= 0:
+            assert match[p, r] == order[0]
+    # the oracle on a sample of pairs
+    for p in rng.integers(96, P, 12):
+        wc, wm, wbd, wsd, _ = orc.bf2nn(kfs[pa[p]], kfs[pb[p]], 0.75, 50)
+        assert counts[p] == wc and np.array_equal(match[p], wm) and np.array_equal(bd[p], wbd) and np.array_equal(sd[p], wsd)
+    ctx.free_frames(ids)
