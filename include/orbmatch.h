@@ -158,6 +158,8 @@ int orbm_bowvecs_free(orbm_ctx *ctx, int n_vecs, const int32_t *ids);
  * of words both hold.  With io_on_device the id lists and outputs are device addresses and the ids are not checked. */
 int orbm_bow_score_batch(orbm_ctx *ctx, int n_pairs, const int32_t *vec_a, const int32_t *vec_b, double *score,
                          int32_t *common, int io_on_device);
+/* Copies a device-resident BowVector to the host (n words; the arrays hold `capacity` entries). */
+int orbm_bowvec_download(orbm_ctx *ctx, int32_t id, int32_t *n, uint32_t *word, double *value, int32_t capacity);
 
 /* ---- DBoW2 TemplatedVocabulary::transform(features, ..., FeatureVector, levelsup), word / node part,
  * as called by Frame::ComputeBoW (Frame.cc:526-533) and KeyFrame::ComputeBoW (KeyFrame.cc:69-78) with levelsup = 4.
@@ -173,6 +175,8 @@ typedef struct orbm_vocab_view {
     const uint8_t *desc;         /* n_nodes x 32 */
     const int32_t *word_id;      /* n_nodes */
     const double *weight;        /* n_nodes or NULL */
+    int32_t weighting;           /* DBoW2 WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (ORBvoc.txt: 0) */
+    int32_t scoring;             /* DBoW2 ScoringType: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT (ORBvoc.txt: 0) */
 } orbm_vocab_view;
 int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *vocab, int32_t *vocab_id);
 int orbm_vocab_free(orbm_ctx *ctx, int32_t vocab_id);
@@ -181,9 +185,12 @@ int orbm_vocab_free(orbm_ctx *ctx, int32_t vocab_id);
  * feature indices ascending inside a node), so that orbm_search_bow_batch / orbm_search_triang_batch need no
  * FeatureVector from the host.  word_id / node_id (host, n_frames x stride, nullable) receive the per-feature word id
  * and node id (node id -1: the word's weight is not positive, the feature is in no node); rows beyond a frame's n are
- * -1.  Limit: 8192 features per frame. */
+ * -1.  bowvec_ids (host, n_frames, nullable): also builds each frame's BowVector on the device (word weights added per
+ * feature in feature order, L1-normalised in word order, as transform() does for the vocabulary's weighting / scoring;
+ * not for L2_NORM) and returns their ids for orbm_bow_score_batch; release them with orbm_bowvecs_free.
+ * Limit: 8192 features per frame. */
 int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_frames, const int32_t *frames, int levelsup,
-                            int32_t stride, int32_t *word_id, int32_t *node_id);
+                            int32_t stride, int32_t *word_id, int32_t *node_id, int32_t *bowvec_ids);
 /* The same descent for n bare descriptors (32 bytes each; host, or device and 16-byte aligned when io_on_device):
  * word_id[n], node_id[n] as above.  What a per-call ORBVocabulary::transform needs before a frame exists. */
 int orbm_vocab_transform(orbm_ctx *ctx, int32_t vocab_id, int n, const uint8_t *desc, int levelsup, int32_t *word_id,

@@ -50,7 +50,7 @@ def lib():
         L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
         L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
         L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
-        L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p]
+        L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p, i32p, u32p, C.POINTER(C.c_double)]
         L.orc_bow_score.argtypes = [C.POINTER(CBowVecView), C.POINTER(CBowVecView), i32p]
         L.orc_bow_score.restype = C.c_double
         L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
@@ -187,8 +187,8 @@ def predict_scale(max_distance, current_dist, log_scale_factor, n_levels) -> int
     return int(lib().orc_predict_scale(max_distance, current_dist, log_scale_factor, n_levels))
 
 
-def transform(vocab, desc, levelsup: int):
-    """-> word_id[n], node_id[n] (-1: weight not positive), (fv_node, fv_off, fv_idx)"""
+def transform(vocab, desc, levelsup: int, want_bow: bool = False):
+    """-> word_id[n], node_id[n] (-1: weight not positive), (fv_node, fv_off, fv_idx) [, (bv_word, bv_value)]"""
     d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     n = len(d)
     word = np.zeros(max(n, 1), np.int32)
@@ -196,10 +196,18 @@ def transform(vocab, desc, levelsup: int):
     fv_node = np.zeros(max(n, 1), np.uint32)
     fv_off = np.zeros(n + 1, np.uint32)
     fv_idx = np.zeros(max(n, 1), np.uint32)
+    bv_n = C.c_int32(0)
+    bv_word = np.zeros(max(n, 1), np.uint32)
+    bv_value = np.zeros(max(n, 1), np.float64)
     v = vocab.view()
     nn = lib().orc_transform(C.byref(v), _p(d, C.c_uint8) if n else None, n, levelsup, _p(word, C.c_int32), _p(node, C.c_int32),
-                             _p(fv_node, C.c_uint32), _p(fv_off, C.c_uint32), _p(fv_idx, C.c_uint32))
-    return word[:n], node[:n], (fv_node[:nn].copy(), fv_off[:nn + 1].copy(), fv_idx[:int(fv_off[nn])].copy())
+                             _p(fv_node, C.c_uint32), _p(fv_off, C.c_uint32), _p(fv_idx, C.c_uint32),
+                             C.byref(bv_n), _p(bv_word, C.c_uint32), _p(bv_value, C.c_double))
+    out = (word[:n], node[:n], (fv_node[:nn].copy(), fv_off[:nn + 1].copy(), fv_idx[:int(fv_off[nn])].copy()))
+    if want_bow:
+        k = int(bv_n.value)
+        out = out + ((bv_word[:k].copy(), bv_value[:k].copy()),)
+    return out
 
 
 def bow_score(a, b):

@@ -690,7 +690,7 @@ int orc_distinctive_descriptor(const uint8_t *desc, int n) {
 // call it.  The tree is rebuilt from the flat view into DBoW2's own shape (a vector of nodes with child-id vectors) and the
 // FeatureVector is the std::map<NodeId, std::vector<unsigned>> that FeatureVector::addFeature fills.
 int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out,
-                  uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx) {
+                  uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx, int32_t *bv_n, uint32_t *bv_word, double *bv_value) {
     struct Node {
         std::vector<uint32_t> children;
         const uint8_t *descriptor;
@@ -707,6 +707,11 @@ int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int leve
         nd.word_id = V->word_id[i];
     }
     const int m_L = V->depth;
+    // BowVector part of transform(): LNorm norm; bool must = m_scoring_object->mustNormalize(norm);
+    const bool tf = V->weighting == 0 || V->weighting == 1;                  // TF_IDF, TF
+    const bool must = V->scoring != 5;                                       // every scoring but DOT_PRODUCT normalises
+    const bool l2 = V->scoring == 1;                                         // L2_NORM -> L2, the others -> L1
+    std::map<uint32_t, double> v;
     std::map<uint32_t, std::vector<unsigned int>> fv;
     for (int i_feature = 0; i_feature < n; i_feature++) {
         const uint8_t *feature = desc + 32 * (size_t)i_feature;
@@ -737,6 +742,14 @@ int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int leve
         if (word_out) word_out[i_feature] = word_id;
         if (node_out) node_out[i_feature] = w > 0 ? (int32_t)nid : -1;
         if (w > 0) {   // not stopped
+            {   // v.addWeight(id, w)  /  v.addIfNotExist(id, w)
+                auto bit = v.lower_bound((uint32_t)word_id);
+                if (bit != v.end() && bit->first == (uint32_t)word_id) {
+                    if (tf) bit->second += w;
+                } else {
+                    v.insert(bit, std::make_pair((uint32_t)word_id, w));
+                }
+            }
             // FeatureVector::addFeature(nid, i_feature)
             auto vit = fv.lower_bound(nid);
             if (vit != fv.end() && vit->first == nid)
@@ -746,6 +759,26 @@ int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int leve
                 vit->second.push_back(i_feature);
             }
         }
+    }
+    if (tf && !v.empty() && !must) {   // unnecessary when normalizing
+        const double nd = v.size();
+        for (auto &kv : v) kv.second /= nd;
+    }
+    if (must) {                        // BowVector::normalize(norm)
+        double norm = 0.0;
+        if (!l2) {
+            for (auto &kv : v) norm += fabs(kv.second);
+        } else {
+            for (auto &kv : v) norm += kv.second * kv.second;
+            norm = sqrt(norm);
+        }
+        if (norm > 0.0)
+            for (auto &kv : v) kv.second /= norm;
+    }
+    if (bv_n) {
+        int t = 0;
+        for (auto &kv : v) { bv_word[t] = kv.first; bv_value[t] = kv.second; t++; }
+        *bv_n = t;
     }
     int j = 0;
     uint32_t pos = 0;

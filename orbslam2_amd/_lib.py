@@ -16,7 +16,7 @@ SYMBOLS = [
     "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_stereo_match_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
     "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
     "orbm_vocab_upload", "orbm_vocab_free", "orbm_frames_compute_bow", "orbm_vocab_transform", "orbm_frame_fv_download",
-    "orbm_bowvecs_upload", "orbm_bowvecs_free", "orbm_bow_score_batch",
+    "orbm_bowvecs_upload", "orbm_bowvecs_free", "orbm_bow_score_batch", "orbm_bowvec_download",
     "orbm_popcount_peak",
 ]
 
@@ -62,11 +62,12 @@ def load():
     L.orbm_search_init.argtypes = [vp, i32, i32, vp, C.c_int, f32, C.c_int, vp]
     L.orbm_vocab_upload.argtypes = [vp, C.POINTER(CVocabView), C.POINTER(i32)]
     L.orbm_vocab_free.argtypes = [vp, i32]
-    L.orbm_frames_compute_bow.argtypes = [vp, i32, C.c_int, vp, C.c_int, i32, vp, vp]
+    L.orbm_frames_compute_bow.argtypes = [vp, i32, C.c_int, vp, C.c_int, i32, vp, vp, vp]
     L.orbm_vocab_transform.argtypes = [vp, i32, C.c_int, vp, C.c_int, vp, vp, C.c_int]
     L.orbm_frame_fv_download.argtypes = [vp, i32, C.POINTER(i32), vp, vp, vp]
     L.orbm_bowvecs_upload.argtypes = [vp, C.c_int, C.POINTER(CBowVecView), vp]
     L.orbm_bowvecs_free.argtypes = [vp, C.c_int, vp]
+    L.orbm_bowvec_download.argtypes = [vp, i32, C.POINTER(i32), vp, vp, i32]
     L.orbm_bow_score_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int]
     L.orbm_popcount_peak.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in SYMBOLS:

@@ -57,21 +57,15 @@ __global__ __launch_bounds__(64) void bow_score_kernel(const BowVecDev *__restri
 
 }  // namespace
 
-extern "C" int orbm_bowvecs_upload(orbm_ctx *ctx, int n_vecs, const orbm_bowvec_view *views, int32_t *out_ids) {
-    if (!ctx) return ORBM_EINVAL;
-    if (n_vecs < 0 || (n_vecs > 0 && (!views || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "bowvecs_upload: null argument");
-    if (n_vecs == 0) return ORBM_OK;
+// Table entries + one arena for n_vecs BowVectors of the given capacities; entry k starts with n_init[k] words (the
+// caller fills the arrays: copy for an upload, a kernel for ComputeBoW).  o_word / o_val: byte offsets into the arena.
+int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
+                       std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes) {
     size_t total = 0;
-    std::vector<size_t> o_word(n_vecs), o_val(n_vecs);
+    o_word.resize(n_vecs); o_val.resize(n_vecs);
     for (int k = 0; k < n_vecs; k++) {
-        const orbm_bowvec_view &v = views[k];
-        if (v.n < 0 || v.n > BVEC_MAX_WORDS) return orbm_fail(ctx, ORBM_ELIMIT, "bowvec %d: n = %d outside [0, %d]", k, v.n, BVEC_MAX_WORDS);
-        if (v.n > 0 && (!v.word || !v.value)) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: null array", k);
-        for (int i = 1; i < v.n; i++)
-            if (v.word[i] <= v.word[i - 1]) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: word ids not strictly ascending at %d", k, i);
-        if (v.n > 0 && v.word[v.n - 1] == 0xFFFFFFFFu) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: word id 0xFFFFFFFF is reserved", k);
-        o_val[k] = total; total += (((size_t)v.n * 8 + 255) / 256) * 256;
-        o_word[k] = total; total += (((size_t)v.n * 4 + 255) / 256) * 256;
+        o_val[k] = total; total += (((size_t)cap[k] * 8 + 255) / 256) * 256;
+        o_word[k] = total; total += (((size_t)cap[k] * 4 + 255) / 256) * 256;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Arena ar;
@@ -80,14 +74,11 @@ extern "C" int orbm_bowvecs_upload(orbm_ctx *ctx, int n_vecs, const orbm_bowvec_
     int arena_id = -1;
     for (size_t i = 0; i < ctx->bvec_arenas.size(); i++) if (!ctx->bvec_arenas[i].base) { arena_id = (int)i; break; }
     if (arena_id < 0) { ctx->bvec_arenas.push_back(ar); arena_id = (int)ctx->bvec_arenas.size() - 1; } else ctx->bvec_arenas[arena_id] = ar;
-    std::vector<uint8_t> host(std::max(total, (size_t)1), 0);
     char *b = (char *)ar.base;
     size_t lo = SIZE_MAX, hi = 0;
     for (int k = 0; k < n_vecs; k++) {
-        const orbm_bowvec_view &v = views[k];
-        if (v.n > 0) { memcpy(host.data() + o_val[k], v.value, (size_t)v.n * 8); memcpy(host.data() + o_word[k], v.word, (size_t)v.n * 4); }
         BowVecDev d;
-        d.n = v.n; d.word = (const uint32_t *)(b + o_word[k]); d.value = (const double *)(b + o_val[k]);
+        d.n = n_init[k]; d.word = (const uint32_t *)(b + o_word[k]); d.value = (const double *)(b + o_val[k]);
         int32_t id;
         if (!ctx->free_bvecs.empty()) { id = ctx->free_bvecs.back(); ctx->free_bvecs.pop_back(); ctx->h_bvecs[id] = d; ctx->bvec_arena[id] = arena_id; }
         else { id = (int32_t)ctx->h_bvecs.size(); ctx->h_bvecs.push_back(d); ctx->bvec_arena.push_back(arena_id); }
@@ -104,17 +95,49 @@ extern "C" int orbm_bowvecs_upload(orbm_ctx *ctx, int n_vecs, const orbm_bowvec_
         ctx->d_bvecs = nt; ctx->d_bvecs_cap = ncap;
         lo = 0; hi = ctx->h_bvecs.size() - 1;
     }
-    const size_t tab_bytes = (hi - lo + 1) * sizeof(BowVecDev), o_tab = ((total + 255) / 256) * 256;
-    if (char *pin = (char *)orbm_pin_up(ctx, o_tab + tab_bytes)) {
-        if (total) memcpy(pin, host.data(), total);
-        memcpy(pin + o_tab, ctx->h_bvecs.data() + lo, tab_bytes);
-        if (total) HIPCHK(ctx, hipMemcpyAsync(ar.base, pin, total, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_bvecs + lo, pin + o_tab, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the table rows travel stream-ordered from a private copy (the vector may grow before the copy has run)
+    const size_t tab_bytes = (hi - lo + 1) * sizeof(BowVecDev);
+    if (char *pin = (char *)orbm_pin_up(ctx, tab_bytes)) {
+        memcpy(pin, ctx->h_bvecs.data() + lo, tab_bytes);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_bvecs + lo, pin, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // the pinned block is reused by the next upload
     } else {
-        if (total) HIPCHK(ctx, hipMemcpy(ar.base, host.data(), total, hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(ctx->d_bvecs + lo, ctx->h_bvecs.data() + lo, tab_bytes, hipMemcpyHostToDevice));
     }
+    *arena_base = ar.base;
+    *total_bytes = total;
+    return ORBM_OK;
+}
+
+extern "C" int orbm_bowvecs_upload(orbm_ctx *ctx, int n_vecs, const orbm_bowvec_view *views, int32_t *out_ids) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_vecs < 0 || (n_vecs > 0 && (!views || !out_ids))) return orbm_fail(ctx, ORBM_EINVAL, "bowvecs_upload: null argument");
+    if (n_vecs == 0) return ORBM_OK;
+    std::vector<int32_t> ns(n_vecs);
+    for (int k = 0; k < n_vecs; k++) {
+        const orbm_bowvec_view &v = views[k];
+        if (v.n < 0 || v.n > BVEC_MAX_WORDS) return orbm_fail(ctx, ORBM_ELIMIT, "bowvec %d: n = %d outside [0, %d]", k, v.n, BVEC_MAX_WORDS);
+        if (v.n > 0 && (!v.word || !v.value)) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: null array", k);
+        for (int i = 1; i < v.n; i++)
+            if (v.word[i] <= v.word[i - 1]) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: word ids not strictly ascending at %d", k, i);
+        if (v.n > 0 && v.word[v.n - 1] == 0xFFFFFFFFu) return orbm_fail(ctx, ORBM_EINVAL, "bowvec %d: word id 0xFFFFFFFF is reserved", k);
+        ns[k] = v.n;
+    }
+    std::vector<size_t> o_word, o_val;
+    void *base = nullptr;
+    size_t total = 0;
+    int rc = orbm_bvecs_reserve(ctx, n_vecs, ns.data(), ns.data(), out_ids, &base, o_word, o_val, &total);
+    if (rc) return rc;
+    if (total == 0) return ORBM_OK;
+    char *pin = (char *)orbm_pin_up(ctx, total);
+    std::vector<uint8_t> pageable;
+    if (!pin) { pageable.resize(total); pin = (char *)pageable.data(); }
+    for (int k = 0; k < n_vecs; k++) {
+        const orbm_bowvec_view &v = views[k];
+        if (v.n > 0) { memcpy(pin + o_val[k], v.value, (size_t)v.n * 8); memcpy(pin + o_word[k], v.word, (size_t)v.n * 4); }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(base, pin, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ORBM_OK;
 }
 
@@ -173,4 +196,22 @@ extern "C" int orbm_bow_score_batch(orbm_ctx *ctx, int n_pairs, const int32_t *v
                        (const int32_t *)db, (double *)ds, (int32_t *)dc);
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
+}
+
+extern "C" int orbm_bowvec_download(orbm_ctx *ctx, int32_t id, int32_t *n, uint32_t *word, double *value, int32_t capacity) {
+    if (!ctx) return ORBM_EINVAL;
+    if (!n) return orbm_fail(ctx, ORBM_EINVAL, "bowvec_download: null argument");
+    int rc = check_bvecs(ctx, 1, &id, "id");
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const BowVecDev &h = ctx->h_bvecs[id];
+    *n = h.n;
+    if (h.n > capacity) return orbm_fail(ctx, ORBM_EINVAL, "bowvec_download: %d words, room for %d", h.n, capacity);
+    if (h.n > 0) {
+        if (!word || !value) return orbm_fail(ctx, ORBM_EINVAL, "bowvec_download: null array");
+        HIPCHK(ctx, hipMemcpy(word, h.word, (size_t)h.n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(value, h.value, (size_t)h.n * 8, hipMemcpyDeviceToHost));
+    }
+    return ORBM_OK;
 }

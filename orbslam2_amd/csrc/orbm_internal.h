@@ -57,6 +57,8 @@ struct VocabDev {
     const uint2 *node_rec = nullptr;
     const uint32_t *child_idx = nullptr, *desc = nullptr;
     const int32_t *word_id = nullptr;
+    const double *weight = nullptr;     // per node
+    int32_t weighting = 0, scoring = 0; // DBoW2 WeightingType / ScoringType
     Arena arena;
 };
 
@@ -126,6 +128,8 @@ int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
 void *orbm_pin_up(orbm_ctx *ctx, size_t bytes);      // pinned upload staging of at least `bytes`, or null (too large / failed)
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
 int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
+int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
+                       std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
 
 // Helper that stages host index lists / outputs through the I/O workspace when io_on_device == 0.

@@ -29,7 +29,7 @@ constexpr int VOC_MAX_CHILDREN = 65535;
 // wave-uniform (descents that reached a leaf idle until the whole wave has), loads of lanes without a child go to
 // row 0, so the cross-lane steps never read a lane that sits out.
 template <int NF>
-__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ const (&g)[NF], int levelsup, int32_t (&word)[NF], int (&nid)[NF]) {
+__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ const (&g)[NF], int levelsup, int32_t (&word)[NF], int (&nid)[NF], int (&leaf)[NF]) {
     const uint32_t sub = threadIdx.x & (VOC_GROUP - 1);
     uint32_t q[NF][8];
 #pragma unroll
@@ -96,13 +96,14 @@ __device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restri
             }
     }
 #pragma unroll
-    for (int u = 0; u < NF; u++) word[u] = V.word_id[final_id[u]];       // bit 31: the word's weight is not positive
+    for (int u = 0; u < NF; u++) { word[u] = V.word_id[final_id[u]]; leaf[u] = (int)final_id[u]; }       // bit 31 of word: the word's weight is not positive
 }
 
 template <int NF>
 __global__ __launch_bounds__(256) void transform_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ ids,
                                                         VocabDev V, int levelsup, int blocks_per_frame, int stride,
-                                                        int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
+                                                        int32_t *__restrict__ word_out, int32_t *__restrict__ node_out,
+                                                        int32_t *__restrict__ leaf_out) {
     const int f = blockIdx.x / blocks_per_frame;
     const int i0 = ((blockIdx.x - f * blocks_per_frame) * (256 / VOC_GROUP) + (int)(threadIdx.x / VOC_GROUP)) * NF;
     const FrameDev &F = table[ids[f]];
@@ -111,14 +112,15 @@ __global__ __launch_bounds__(256) void transform_kernel(const FrameDev *__restri
     const uint4 *g[NF];
 #pragma unroll
     for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)min(i0 + u, n - 1);
-    int32_t w[NF]; int nid[NF];
-    descend<NF>(V, g, levelsup, w, nid);
+    int32_t w[NF]; int nid[NF], leaf[NF];
+    descend<NF>(V, g, levelsup, w, nid, leaf);
     const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
 #pragma unroll
     for (int u = 0; u < NF; u++)
         if (sub == u && i0 + u < n) {
             word_out[(size_t)f * stride + i0 + u] = w[u] & 0x7FFFFFFF;
             node_out[(size_t)f * stride + i0 + u] = w[u] < 0 ? -1 : nid[u];
+            if (leaf_out) leaf_out[(size_t)f * stride + i0 + u] = w[u] < 0 ? -1 : leaf[u];
         }
 }
 
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void transform_flat_kernel(const uint32_t *__r
     const uint4 *g[NF];
 #pragma unroll
     for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)min(i0 + u, n - 1);
-    int32_t w[NF]; int nid[NF];
-    descend<NF>(V, g, levelsup, w, nid);
+    int32_t w[NF]; int nid[NF], leaf[NF];
+    descend<NF>(V, g, levelsup, w, nid, leaf);
     const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
 #pragma unroll
     for (int u = 0; u < NF; u++)
@@ -206,6 +208,93 @@ __global__ __launch_bounds__(FVB_THREADS) void fv_build_kernel(FrameDev *__restr
     if (tid == 0) { fv_off[total] = (uint32_t)n; F.n_nodes = (int32_t)total; n_nodes_out[f] = (int32_t)total; }
 }
 
+// BowVector of each frame (TemplatedVocabulary::transform, BowVector part): words ascending; value = the weights of the
+// word's features added one by one in feature order (addWeight), or the first one only (addIfNotExist, IDF / BINARY
+// weighting); then divided by the L1 norm, itself a sum over the words in ascending order (BowVector::normalize), or by
+// the number of words when the scoring does not normalise.  Both sums are sequential in DBoW2 and so they are here:
+// one thread per word adds its features' weights, thread 0 adds the norm.  leaf_in = leaf node per feature, -1 = left out.
+__global__ __launch_bounds__(FVB_THREADS) void bv_build_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int stride,
+                                                               const int32_t *__restrict__ word_in, const int32_t *__restrict__ leaf_in,
+                                                               VocabDev V, BowVecDev *__restrict__ bv_table, const int32_t *__restrict__ bv_ids,
+                                                               int32_t *__restrict__ n_words_out) {
+    extern __shared__ __align__(16) unsigned long long keys[];       // m keys, then m doubles
+    __shared__ uint32_t part[FVB_THREADS];
+    __shared__ int n_in;
+    __shared__ double norm_sh;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n_feat = table[ids[f]].n;
+    int m = 1;
+    while (m < n_feat) m <<= 1;
+    double *sums = reinterpret_cast<double *>(keys + max(m, 2));
+    if (tid == 0) n_in = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < m; i += FVB_THREADS) {
+        const bool in = i < n_feat && leaf_in[(size_t)f * stride + i] >= 0;
+        keys[i] = in ? ((unsigned long long)(uint32_t)word_in[(size_t)f * stride + i] << 32) | (uint32_t)i : ~0ull;
+        mine += in;
+    }
+    if (mine) atomicAdd(&n_in, mine);
+    __syncthreads();
+    const int n = n_in;
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (m >> 1); t += FVB_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    BowVecDev &out = bv_table[bv_ids[f]];
+    uint32_t *o_word = const_cast<uint32_t *>(out.word);
+    double *o_val = const_cast<double *>(out.value);
+    const int per = (n + FVB_THREADS - 1) / FVB_THREADS;
+    const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
+    uint32_t heads = 0;
+    for (int p = p0; p < p1; p++) heads += (p == 0 || (keys[p] >> 32) != (keys[p - 1] >> 32)) ? 1u : 0u;
+    part[tid] = heads;
+    __syncthreads();
+    for (int d = 1; d < FVB_THREADS; d <<= 1) {
+        const uint32_t add = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t base = part[tid] - heads;
+    const int n_words = (int)part[FVB_THREADS - 1];
+    const bool accumulate = V.weighting == 0 || V.weighting == 1;          // TF_IDF, TF
+    for (int p = p0; p < p1; p++) {
+        const unsigned long long kp = keys[p];
+        if (p == 0 || (kp >> 32) != (keys[p - 1] >> 32)) {
+            // run head: this thread owns the whole run (it may extend into the next thread's positions)
+            double acc = V.weight[leaf_in[(size_t)f * stride + (uint32_t)kp]];
+            if (accumulate)
+                for (int r = p + 1; r < n && (keys[r] >> 32) == (kp >> 32); r++) acc += V.weight[leaf_in[(size_t)f * stride + (uint32_t)keys[r]]];
+            o_word[base] = (uint32_t)(kp >> 32);
+            sums[base] = acc;
+            base++;
+        }
+    }
+    __syncthreads();
+    const bool l1 = V.scoring != 5;                                        // everything but DOT_PRODUCT (L2_NORM is refused by the host)
+    if (tid == 0) {
+        double norm = 0.0;
+        if (l1) for (int w = 0; w < n_words; w++) norm += fabs(sums[w]);
+        else norm = (double)n_words;
+        norm_sh = norm;
+        out.n = n_words;
+        n_words_out[f] = n_words;
+    }
+    __syncthreads();
+    const double norm = norm_sh;
+    // normalize(): only if the norm is positive; the unnormalised TF case divides by the word count only when accumulating
+    const bool divide = l1 ? norm > 0.0 : (accumulate && n_words > 0);
+    for (int w = tid; w < n_words; w += FVB_THREADS) o_val[w] = divide ? sums[w] / norm : sums[w];
+}
+
 }  // namespace
 
 extern "C" void orbm__vocab_variant(int v) { g_vocab_variant = v; }
@@ -217,6 +306,8 @@ extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_
         return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: empty tree or null array");
     const size_t nn = (size_t)v->n_nodes;
     const uint32_t nchild = v->child_off[nn];
+    if (v->weighting < 0 || v->weighting > 3 || v->scoring < 0 || v->scoring > 5)
+        return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: weighting %d / scoring %d outside DBoW2's enums", v->weighting, v->scoring);
     if (v->child_off[0] != 0 || v->child_off[1] == 0 || !v->child_idx) return orbm_fail(ctx, ORBM_EINVAL, "vocab_upload: bad child_off or a root without children");
     // every node but the root is the child of exactly one EARLIER node: the descent then always terminates
     std::vector<uint8_t> seen(nn, 0);
@@ -241,7 +332,7 @@ extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t o_off = 0, o_idx = nn * 8, o_desc = ((o_idx + (size_t)nchild * 4 + 255) / 256) * 256;
-    const size_t o_word = o_desc + nn * 32, total = o_word + nn * 4;
+    const size_t o_word = o_desc + nn * 32, o_weight = ((o_word + nn * 4 + 255) / 256) * 256, total = o_weight + nn * 8;
     VocabDev V;
     { int rc = orbm_arena_alloc(ctx, total, &V.arena); if (rc) return rc; }
     char *b = (char *)V.arena.base;
@@ -254,6 +345,13 @@ extern "C" int orbm_vocab_upload(orbm_ctx *ctx, const orbm_vocab_view *v, int32_
         if (leaf && v->weight && !(v->weight[i] > 0)) words[i] |= (int32_t)0x80000000;     // "if (w > 0)" of transform()
     }
     HIPCHK(ctx, hipMemcpy(b + o_word, words.data(), nn * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<double> wts(nn, 1.0);
+        if (v->weight) wts.assign(v->weight, v->weight + nn);
+        HIPCHK(ctx, hipMemcpy(b + o_weight, wts.data(), nn * 8, hipMemcpyHostToDevice));
+    }
+    V.weight = (const double *)(b + o_weight);
+    V.weighting = v->weighting; V.scoring = v->scoring;
     V.n_nodes = v->n_nodes; V.depth = v->depth;
     V.node_rec = (const uint2 *)(b + o_off); V.child_idx = (const uint32_t *)(b + o_idx);
     V.desc = (const uint32_t *)(b + o_desc); V.word_id = (const int32_t *)(b + o_word);
@@ -275,7 +373,7 @@ extern "C" int orbm_vocab_free(orbm_ctx *ctx, int32_t vocab_id) {
 }
 
 extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_frames, const int32_t *frames, int levelsup,
-                                       int32_t stride, int32_t *word_id, int32_t *node_id) {
+                                       int32_t stride, int32_t *word_id, int32_t *node_id, int32_t *bowvec_ids) {
     if (!ctx) return ORBM_EINVAL;
     if (vocab_id < 0 || (size_t)vocab_id >= ctx->vocabs.size() || !ctx->vocabs[vocab_id].arena.base)
         return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: %d is not a live vocabulary", vocab_id);
@@ -290,21 +388,35 @@ extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_fr
     }
     if (max_n > FV_MAX_N) return orbm_fail(ctx, ORBM_ELIMIT, "frames_compute_bow: frames of more than %d features are not supported (got %d)", FV_MAX_N, max_n);
     if ((word_id || node_id) && max_n > stride) return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: stride %d < largest frame %d", stride, max_n);
+    if (bowvec_ids && ctx->vocabs[vocab_id].scoring == 1)
+        return orbm_fail(ctx, ORBM_EINVAL, "frames_compute_bow: BowVectors of an L2_NORM vocabulary are not built on the device");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int st = std::max(std::max(stride, max_n), 1);
     const size_t elems = (size_t)n_frames * st;
-    rc = orbm_ws_reserve(ctx, (size_t)n_frames * 8 + (word_id ? elems * 4 : 0) + (node_id ? elems * 4 : 0) + 4096);
+    rc = orbm_ws_reserve(ctx, (size_t)n_frames * 16 + (word_id ? elems * 4 : 0) + (node_id ? elems * 4 : 0) + 4096);
     if (rc) return rc;
-    rc = orbm_ws2_reserve(ctx, elems * 8 + 512);         // outputs the caller does not ask for stay on the device
+    const size_t col = ((elems * 4 + 255) / 256) * 256;
+    rc = orbm_ws2_reserve(ctx, col * 3 + 512);           // outputs the caller does not ask for stay on the device
     if (rc) return rc;
+    // room for the BowVectors (may grow and re-send the BowVector table)
+    std::vector<size_t> bo_word, bo_val;
+    if (bowvec_ids) {
+        std::vector<int32_t> caps(n_frames), zeros(n_frames, 0);
+        for (int k = 0; k < n_frames; k++) caps[k] = std::max(ctx->h_frames[frames[k]].n, 1);
+        void *base; size_t total;
+        rc = orbm_bvecs_reserve(ctx, n_frames, caps.data(), zeros.data(), bowvec_ids, &base, bo_word, bo_val, &total);
+        if (rc) return rc;
+    }
     IoStage io(ctx, 0);
-    const void *dids; void *dw, *dn, *dnn;
-    std::vector<int32_t> nn(n_frames);
-    if ((rc = io.in(frames, (size_t)n_frames * 4, &dids)) || (rc = io.out(nn.data(), (size_t)n_frames * 4, &dnn)) ||
+    const void *dids, *dbv = nullptr; void *dw, *dn, *dnn, *dnw = nullptr;
+    std::vector<int32_t> nn(n_frames), nw(n_frames);
+    if ((rc = io.in(frames, (size_t)n_frames * 4, &dids)) || (bowvec_ids && (rc = io.in(bowvec_ids, (size_t)n_frames * 4, &dbv))) ||
+        (rc = io.out(nn.data(), (size_t)n_frames * 4, &dnn)) || (bowvec_ids && (rc = io.out(nw.data(), (size_t)n_frames * 4, &dnw))) ||
         (rc = io.out(word_id, elems * 4, &dw)) || (rc = io.out(node_id, elems * 4, &dn)))
         return rc;
     if (!dw) dw = ctx->ws2;
-    if (!dn) dn = (char *)ctx->ws2 + ((elems * 4 + 255) / 256) * 256;
+    if (!dn) dn = (char *)ctx->ws2 + col;
+    int32_t *dleaf = bowvec_ids ? (int32_t *)((char *)ctx->ws2 + 2 * col) : nullptr;
     HIPCHK(ctx, hipMemsetAsync(dw, 0xFF, elems * 4, ctx->stream));         // rows beyond a frame's n stay -1
     HIPCHK(ctx, hipMemsetAsync(dn, 0xFF, elems * 4, ctx->stream));
     const VocabDev &V = ctx->vocabs[vocab_id];
@@ -313,10 +425,10 @@ extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_fr
         const int per_block = 256 / VOC_GROUP * nf, bpf = (max_n + per_block - 1) / per_block;
         if (nf == 4)
             hipLaunchKernelGGL(transform_kernel<4>, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
-                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
+                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn, dleaf);
         else
             hipLaunchKernelGGL(transform_kernel<1>, dim3((unsigned)(n_frames * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames,
-                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn);
+                               (const int32_t *)dids, V, levelsup, bpf, st, (int32_t *)dw, (int32_t *)dn, dleaf);
         HIPCHK(ctx, hipGetLastError());
     }
     int m = 1;
@@ -327,10 +439,19 @@ extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_fr
     hipLaunchKernelGGL(fv_build_kernel, dim3(n_frames), dim3(FVB_THREADS), lds, ctx->stream, ctx->d_frames, (const int32_t *)dids, st,
                        (const int32_t *)dn, (int32_t *)dnn);
     HIPCHK(ctx, hipGetLastError());
+    if (bowvec_ids) {
+        const size_t lds2 = (size_t)std::max(m, 2) * 16;
+        if (lds2 > 48 * 1024)
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bv_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(bv_build_kernel, dim3(n_frames), dim3(FVB_THREADS), lds2, ctx->stream, ctx->d_frames, (const int32_t *)dids, st,
+                           (const int32_t *)dw, (const int32_t *)dleaf, V, ctx->d_bvecs, (const int32_t *)dbv, (int32_t *)dnw);
+        HIPCHK(ctx, hipGetLastError());
+    }
     rc = io.finish();
     if (rc) return rc;
-    // keep the host mirror of the frame table in step (it is re-sent when the table grows)
+    // keep the host mirrors of the tables in step (they are re-sent when a table grows)
     for (int k = 0; k < n_frames; k++) ctx->h_frames[frames[k]].n_nodes = nn[k];
+    if (bowvec_ids) for (int k = 0; k < n_frames; k++) ctx->h_bvecs[bowvec_ids[k]].n = nw[k];
     return ORBM_OK;
 }
 

@@ -163,6 +163,8 @@ int ORBVocabulary::DeviceId() const {
     v.desc = m_flat.desc.data();
     v.word_id = m_flat.word_id.data();
     v.weight = m_flat.weight.data();
+    v.weighting = (int32_t)m_weighting;
+    v.scoring = (int32_t)m_scoring;
     int32_t id = -1;
     detail::HostCheck(orbm_vocab_upload(ctx, &v, &id), "orbm_vocab_upload");
     m[this] = {m_generation, id};

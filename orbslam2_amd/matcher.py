@@ -134,17 +134,28 @@ class Context:
     def free_vocabulary(self, vid: int):
         self._chk(self._L.orbm_vocab_free(self._h, int(vid)))
 
-    def compute_bow(self, vid: int, frames, levelsup: int = 4, stride: int = 0, want_ids: bool = True):
-        """-> (word_id, node_id) [n_frames, stride] when want_ids, else None; the frames' FeatureVectors are replaced."""
+    def compute_bow(self, vid: int, frames, levelsup: int = 4, stride: int = 0, want_ids: bool = True, want_bowvecs: bool = False):
+        """The frames' FeatureVectors are replaced on the device.  -> (word_id, node_id) [n_frames, stride] when want_ids;
+        with want_bowvecs also (or only) the ids of the device-built BowVectors."""
         fr = np.ascontiguousarray(frames, np.int32)
         p = len(fr)
-        if not want_ids:
-            self._chk(self._L.orbm_frames_compute_bow(self._h, int(vid), p, _addr(fr), int(levelsup), int(stride), None, None))
-            return None
-        word = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
-        node = np.full((max(p, 1), max(stride, 1)), -1, np.int32)
-        self._chk(self._L.orbm_frames_compute_bow(self._h, int(vid), p, _addr(fr), int(levelsup), int(stride), _addr(word), _addr(node)))
-        return word[:p], node[:p]
+        bv = np.full(max(p, 1), -1, np.int32) if want_bowvecs else None
+        word = np.full((max(p, 1), max(stride, 1)), -1, np.int32) if want_ids else None
+        node = np.full((max(p, 1), max(stride, 1)), -1, np.int32) if want_ids else None
+        self._chk(self._L.orbm_frames_compute_bow(self._h, int(vid), p, _addr(fr), int(levelsup), int(stride), _addr(word), _addr(node),
+                                                  _addr(bv)))
+        out = ()
+        if want_ids:
+            out += (word[:p], node[:p])
+        if want_bowvecs:
+            out += (bv[:p],)
+        return out if out else None
+
+    def download_bowvec(self, bid: int, capacity: int = 16384):
+        n = C.c_int32(0)
+        word = np.zeros(capacity, np.uint32); value = np.zeros(capacity, np.float64)
+        self._chk(self._L.orbm_bowvec_download(self._h, int(bid), C.byref(n), _addr(word), _addr(value), capacity))
+        return word[: n.value].copy(), value[: n.value].copy()
 
     def transform(self, vid: int, desc: np.ndarray, levelsup: int = 4):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)

@@ -86,6 +86,8 @@ class CVocabView(C.Structure):
         ("desc", _u8p),
         ("word_id", _i32p),
         ("weight", C.POINTER(C.c_double)),
+        ("weighting", C.c_int32),
+        ("scoring", C.c_int32),
     ]
 
 
@@ -259,6 +261,8 @@ class VocabData:
     desc: np.ndarray        # [n_nodes,32] uint8
     word_id: np.ndarray     # [n_nodes] int32, -1 for inner nodes
     weight: Optional[np.ndarray] = None   # [n_nodes] float64
+    weighting: int = 0                    # DBoW2 WeightingType (0 = TF_IDF)
+    scoring: int = 0                      # DBoW2 ScoringType (0 = L1_NORM)
 
     def __post_init__(self):
         self.child_off = _as(self.child_off, np.uint32)
@@ -274,7 +278,8 @@ class VocabData:
     def view(self) -> CVocabView:
         v = CVocabView(n_nodes=self.n_nodes, depth=int(self.depth), child_off=_ptr(self.child_off, C.c_uint32),
                        child_idx=_ptr(self.child_idx, C.c_uint32), desc=_ptr(self.desc, C.c_uint8),
-                       word_id=_ptr(self.word_id, C.c_int32), weight=_ptr(self.weight, C.c_double))
+                       word_id=_ptr(self.word_id, C.c_int32), weight=_ptr(self.weight, C.c_double),
+                       weighting=int(self.weighting), scoring=int(self.scoring))
         v._owner = self
         return v
 

@@ -31,7 +31,8 @@ int orc_search_window(int mode, const orbm_frame_view *F, const orbm_win_queries
 int orc_search_window_free(const orbm_frame_view *F, const orbm_win_queries *Q, int dist_th, int chi2_gate, int32_t *best_idx, uint64_t *ncmp);
 int orc_search_init(const orbm_frame_view *F1, const orbm_frame_view *F2, float *prev_xy, int windowSize, float ratio, int check_ori, int32_t *vnMatches12, uint64_t *ncmp);
 int orc_distinctive_descriptor(const uint8_t *desc, int n);
-int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx);
+int orc_transform(const orbm_vocab_view *V, const uint8_t *desc, int n, int levelsup, int32_t *word_out, int32_t *node_out, uint32_t *fv_node, uint32_t *fv_off, uint32_t *fv_idx,
+                  int32_t *bv_n, uint32_t *bv_word, double *bv_value);
 struct orc_kfdb {
     int32_t n_kf, n_words;
     const orbm_bowvec_view *bow;
@@ -708,7 +709,7 @@ static void TestVocabulary() {
     EXPECT(T.child_off[1] == (uint32_t)k + 1 && T.child_idx[k] == (uint32_t)nn - 1 && T.weight[nn - 1] == 0.0, "end-of-file node");
     orbm_vocab_view V;
     V.n_nodes = nn; V.depth = L; V.child_off = T.child_off.data(); V.child_idx = T.child_idx.data(); V.desc = T.desc.data();
-    V.word_id = T.word_id.data(); V.weight = T.weight.data();
+    V.word_id = T.word_id.data(); V.weight = T.weight.data(); V.weighting = 0; V.scoring = 0;
 
     for (int levelsup : {4, 1, 2, 0}) {
         const int n = 1500;
@@ -725,7 +726,8 @@ static void TestVocabulary() {
         double t1 = NowMs();
         vector<int32_t> word(n), node(n);
         vector<uint32_t> fn(n), fo(n + 1), fi(n);
-        const int nfn = orc_transform(&V, feat[0].b, n, levelsup, word.data(), node.data(), fn.data(), fo.data(), fi.data());
+        int32_t obn = 0; vector<uint32_t> obw(n); vector<double> obv(n);
+        const int nfn = orc_transform(&V, feat[0].b, n, levelsup, word.data(), node.data(), fn.data(), fo.data(), fi.data(), &obn, obw.data(), obv.data());
         EXPECT(node[5] == -1, "the all-zero feature must be left out (node %d)", node[5]);
         EXPECT((int)fv.size() == nfn, "levelsup %d: %zu nodes vs %d", levelsup, fv.size(), nfn);
         int bad = 0, j = 0;
@@ -747,6 +749,8 @@ static void TestVocabulary() {
         int bvbad = bv.size() != want.size();
         for (auto &kv : want) { auto it = bv.find(kv.first); bvbad += it == bv.end() || it->second != kv.second; }
         EXPECT(bvbad == 0, "levelsup %d: %d BowVector mismatches", levelsup, bvbad);
+        int obad = (int)bv.size() != obn; { int t = 0; for (auto &kv : bv) { if (t < obn) obad += kv.first != obw[t] || kv.second != obv[t]; t++; } }
+        EXPECT(obad == 0, "levelsup %d: %d BowVector mismatches against the oracle's transform", levelsup, obad);
         if (levelsup == 4) {
             EXPECT(fv.size() == 1 && fv.begin()->first == 0, "levelsup above the depth: everything in the root");
             printf("ORBVocabulary::transform, %d features, k=%d L=%d: %.2f ms (first call uploads the tree)\n", n, k, L, t1 - t0);

@@ -600,6 +600,9 @@ def test_vocabulary_transform_parity(ctx, orc, case, form):
     from orbslam2_amd import _lib
     kw = _vocab_cases()[case]
     vocab = synth.make_vocabulary(seed=500 + case, **kw)
+    # DBoW2 weighting / scoring of the BowVector: TF_IDF + L1 (ORBvoc.txt), TF + DOT_PRODUCT (divide by the word count),
+    # IDF + L1 and BINARY + DOT_PRODUCT (first weight only), TF_IDF + CHI_SQUARE (L1 norm)
+    vocab.weighting, vocab.scoring = [(0, 0), (1, 5), (2, 0), (3, 5), (0, 2)][case]
     rng = np.random.default_rng(900 + case)
     sizes = [2000, 1, 0, 257, 1023, 4096 if case == 0 else 700]
     frames = []
@@ -611,9 +614,11 @@ def test_vocabulary_transform_parity(ctx, orc, case, form):
     _lib.load().orbm__vocab_variant(form)
     try:
         for levelsup in ([4, 0, 1, 2, vocab.depth, vocab.depth + 3] if case < 3 else [4, 1]):
-            word, node = ctx.compute_bow(vid, ids, levelsup, stride=max(sizes))
+            word, node, bvids = ctx.compute_bow(vid, ids, levelsup, stride=max(sizes), want_bowvecs=True)
             for k, f in enumerate(frames):
-                w_want, n_want, (fn, fo, fi) = orc.transform(vocab, f.desc, levelsup)
+                w_want, n_want, (fn, fo, fi), (bw, bv) = orc.transform(vocab, f.desc, levelsup, want_bow=True)
+                gw, gv = ctx.download_bowvec(bvids[k])
+                assert np.array_equal(gw, bw) and np.array_equal(gv.view(np.uint64), bv.view(np.uint64)), (case, levelsup, k)
                 assert np.array_equal(word[k, :f.n], w_want), (case, levelsup, k)
                 assert np.array_equal(node[k, :f.n], n_want), (case, levelsup, k)
                 assert (word[k, f.n:] == -1).all() and (node[k, f.n:] == -1).all()
@@ -622,6 +627,7 @@ def test_vocabulary_transform_parity(ctx, orc, case, form):
                 if k < 2 or f.n == 0:                      # the same descent on bare descriptors
                     w2, n2 = ctx.transform(vid, f.desc, levelsup)
                     assert np.array_equal(w2, w_want) and np.array_equal(n2, n_want)
+            ctx.free_bowvecs(bvids)
         # the same call without the id outputs leaves the same FeatureVectors
         ctx.compute_bow(vid, ids[:2], 2, want_ids=False)
         _, _, (fn, fo, fi) = orc.transform(vocab, frames[0].desc, 2)
@@ -723,3 +729,45 @@ def test_bow_score_parity(ctx, orc):
     with pytest.raises(OrbmError):
         ctx.bow_score([bid[0]], [ids[0]])                             # freed
     ctx.free_bowvecs(ids)
+
+
+@pytest.mark.gpu
+def test_relocalisation_chain_stays_on_the_device(ctx, orc):
+    """Config 4 end to end without a host-built BoW structure: keyframes and a query frame uploaded with descriptors
+    only -> ComputeBoW on the device (FeatureVector + BowVector) -> the query's BowVector scored against every keyframe
+    -> the best-scoring keyframes matched with SearchByBoW(KF, F) in one batch.  Every stage equals the restated
+    reference chain (transform -> L1 score -> SearchByBoW) on the host."""
+    from orbslam2_amd.views import BowVecData
+    vocab = synth.make_vocabulary(seed=71, k=10, depth=4, flip=0.15)
+    rng = np.random.default_rng(72)
+    lm = synth.vocabulary_features(rng, vocab, 6000, flip=0.05)
+    n_kf, n = 40, 1200
+    frames = []
+    for k in range(n_kf + 1):                                  # keyframe k sees landmarks around 140 * k; the query sits at keyframe 17
+        centre = 140 * (17 if k == n_kf else k)
+        sel = (centre + rng.integers(0, 1600, n)) % 6000
+        flags = np.where(rng.random(n) < 0.9, MP_PRESENT, 0).astype(np.uint8)
+        frames.append(synth.make_frame(rng, lm, sel, with_fv=False, mp_flags=flags))
+    ids = ctx.upload_frames(frames)
+    vid = ctx.upload_vocabulary(vocab)
+    try:
+        (bv,) = ctx.compute_bow(vid, ids, 4, want_ids=False, want_bowvecs=True)
+        score, common = ctx.bow_score(np.full(n_kf, bv[n_kf]), bv[:n_kf])
+        host = []
+        for f in frames:
+            _, _, (f.fv_node, f.fv_off, f.fv_idx), (bw, bvv) = orc.transform(vocab, f.desc, 4, want_bow=True)
+            host.append(BowVecData(bw, bvv))
+        want = [orc.bow_score(host[n_kf], host[k]) for k in range(n_kf)]
+        assert np.array_equal(score.view(np.uint64), np.array([w[0] for w in want]).view(np.uint64))
+        assert np.array_equal(common, [w[1] for w in want])
+        cand = np.argsort(-score, kind="stable")[:8]
+        assert 17 in cand[:3]
+        counts, match = ctx.search_bow(0, ids[cand], np.full(8, ids[n_kf]), 0.75, True, stride=n)
+        for t, k in enumerate(cand):
+            c, m, _ = orc.search_bow(0, frames[k], frames[n_kf], 0.75, True)
+            assert counts[t] == c and np.array_equal(match[t, :n], m), k
+        assert counts[list(cand).index(17)] > 50
+        ctx.free_bowvecs(bv)
+    finally:
+        ctx.free_vocabulary(vid)
+        ctx.free_frames(ids)

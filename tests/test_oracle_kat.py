@@ -261,3 +261,21 @@ def test_bow_l1_score_known_answers(orc):
     assert orc.bow_score(v, v) == (1.0, 2)
     d = BowVecData([2, 3], [0.5, 0.5]); e = BowVecData([], [])
     assert orc.bow_score(v, d) == (0.0, 0) and orc.bow_score(v, e) == (0.0, 0) and orc.bow_score(e, e) == (0.0, 0)
+
+
+def test_vocabulary_bowvector_known_answers(orc):
+    """BowVector part of transform() on the tiny tree with weights 3->1, 4->2, 5->4, 6->8: the five features fall into
+    words [0, 1, 0, 2, 1]: TF_IDF sums 1+1 = 2, 2+2 = 4, 4 -> L1 norm 10 -> {0: .2, 1: .4, 2: .4}; BINARY + DOT_PRODUCT keeps
+    the first weight and does not normalise -> {0: 1, 1: 2, 2: 4}; TF + DOT_PRODUCT divides the sums by the 3 words."""
+    w = np.array([0, 0, 0, 1, 2, 4, 8], np.float64)
+    f = np.zeros((5, 32), np.uint8)
+    f[1, 0] = 0x07; f[2, 0] = 0x03; f[3] = 255; f[4, :16] = 255
+    v = _tiny_vocab(w)
+    *_, (bw, bv) = orc.transform(v, f, 1, want_bow=True)
+    assert bw.tolist() == [0, 1, 2] and bv.tolist() == [2 / 10, 4 / 10, 4 / 10]
+    v.weighting, v.scoring = 3, 5
+    *_, (bw, bv) = orc.transform(v, f, 1, want_bow=True)
+    assert bw.tolist() == [0, 1, 2] and bv.tolist() == [1.0, 2.0, 4.0]
+    v.weighting, v.scoring = 1, 5
+    *_, (bw, bv) = orc.transform(v, f, 1, want_bow=True)
+    assert bv.tolist() == [2 / 3, 4 / 3, 4 / 3]
