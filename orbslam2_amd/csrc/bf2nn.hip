@@ -1,5 +1,9 @@
 // bf2nn.hip -- brute-force 2-NN + threshold + ratio test over keyframe pairs (BASELINE config 2 and the
-// brute-force variant of config 5).  Integer-VALU (popcount) bound.
+// brute-force variant of config 5).  Three forms with identical results:
+//   * bf2nn_mfma4_kernel (default): Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA);
+//   * bf2nn_mfma_kernel: the same through int8 MFMA;
+//   * bf2nn_kernel: xor + popcount on the vector ALU (described next), the form the reference's arithmetic maps to
+//     directly; kept as the cross-check of the other two and for callers that do not want the +-1 frame images.
 //
 // Measured on gfx950 (scripts/ubench_valu2.hip): v_xor/v_and/v_or/v_add issue in ~2 cycles per wave64
 // instruction, v_bcnt_u32_b32 / v_min_u32 / v_med3_u32 / v_lshl_or_b32 / v_cmp in ~4.  One 256-bit
@@ -194,6 +198,260 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
     if ((tid & 63) == 0 && accepted) atomicAdd(&counts[p], accepted);
 }
 
+// ---- MFMA form ---------------------------------------------------------------------------------------------------------
+// With every bit as a +-1 int8 (FrameDev::desc8), the dot product of two rows is (#equal bits - #different bits) =
+// 256 - 2 * hamming: one v_mfma_i32_32x32x32_i8 produces 32 x 32 such dots over 32 of the 256 bit positions, 8 of them a
+// tile of 1024 exact Hamming distances in 8 x 32 cycles -- against ~960 cycles of xor + popcount on the vector ALU.
+// Operand A = 32 candidate rows (from LDS), operand B = 32 query rows (held in registers for the whole kernel), so in the
+// result a lane holds ONE query (column lane & 31) and 16 candidates (rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).
+// Any k order works as long as A and B use the same one (both fragments are bytes [32 s + 16 h, + 16) of a row).
+// Per tile and query the 16 dots are folded with v_max3_i32 and compared with the lane's threshold
+// T = 256 - 2 * min(second best, track_below): only if some lane of the wave beats it does the wave run the exact update
+// (key = dist << 16 | index; second = med3(best, second, key); best = min(best, key)) -- the same rule and the same
+// track_below argument as bf2nn_kernel above.  The two lanes that share a query merge their top-2 at the end.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MF_ROWS = 128;       // candidate rows per LDS stage (32 KB of int8)
+
+template <bool WANT_DIST, int DIAG>
+__global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restrict__ table,
+                                                         const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
+                                                         int blocks_per_pair, float ratio, int th, int track_below, int stride,
+                                                         int32_t *__restrict__ match, int32_t *__restrict__ best_d,
+                                                         int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
+    // 16-byte chunk c of row r sits at chunk position c ^ (r & 15): conflict-free ds_read_b128 for 16 rows at one k step
+    __shared__ v4i tile[MF_ROWS * 16];
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = bid / blocks_per_pair;
+    const int qb = bid - p * blocks_per_pair;
+    const FrameDev &A = table[fa[p]];
+    const FrameDev &B = table[fb[p]];
+    const int nA = A.n, nB = B.n;
+    if (qb * 256 >= nA) return;        // whole block idle (uniform)
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
+    const int nA8 = max(32, (nA + 31) & ~31), nB8 = (nB + 31) & ~31;
+    const int qbase = qb * 256 + wave * 64;
+
+    v4i bq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int row = min(qbase + t * 32 + col, nA8 - 1);
+        const v4i *src = reinterpret_cast<const v4i *>(A.desc8) + (size_t)row * 16;
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[t][s] = src[2 * s + h];
+    }
+    uint32_t best[2], second[2];
+    int T[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        best[t] = (256u << 16) | 0xFFFFu;
+        second[t] = (256u << 16) | 0xFFFFu;
+        T[t] = 256 - 2 * min(256, track_below);
+    }
+
+    const v4i *Bd8 = reinterpret_cast<const v4i *>(B.desc8);
+    for (int c0 = 0; c0 < nB8; c0 += MF_ROWS) {
+        const int rows = min(MF_ROWS, nB8 - c0);            // a multiple of 32
+        if (DIAG != 2 || c0 == 0) {
+            // all loads of the stage first, then the LDS writes (a load-wait-write loop costs one L2 round trip per row group)
+            v4i stg[MF_ROWS * 16 / 256];
+#pragma unroll
+            for (int k = 0; k < MF_ROWS * 16 / 256; k++) {
+                const int i = min(tid + 256 * k, rows * 16 - 1);          // unconditional (clamped): the array stays in registers
+                stg[k] = Bd8[(size_t)c0 * 16 + i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MF_ROWS * 16 / 256; k++) {
+                const int i = tid + 256 * k, r = i >> 4, c = i & 15;
+                if (i < rows * 16) tile[r * 16 + (c ^ (r & 15))] = stg[k];
+            }
+            __syncthreads();
+        }
+        for (int rb = 0; rb < rows; rb += 32) {
+            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+            const v4i *arow = tile + (rb + col) * 16;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const v4i a = arow[(2 * s + h) ^ (col & 15)];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+            }
+            int m0 = max(max(acc0[0], acc0[1]), acc0[2]), m1 = max(max(acc1[0], acc1[1]), acc1[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) {
+                m0 = max(max(m0, acc0[r]), acc0[r + 1]);
+                m1 = max(max(m1, acc1[r]), acc1[r + 1]);
+            }
+            m0 = max(m0, acc0[15]); m1 = max(m1, acc1[15]);
+            if (DIAG == 1) { best[0] += (uint32_t)(m0 + m1); continue; }
+            if (__any(m0 > T[0] || m1 > T[1])) {            // some lane saw dist < its bound: exact update of the tile
+                const int cand0 = c0 + rb + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int cand = cand0 + (r & 3) + 8 * (r >> 2);
+                    const uint32_t k0 = cand < nB ? ((uint32_t)((256 - acc0[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                    const uint32_t k1 = cand < nB ? ((uint32_t)((256 - acc1[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                    second[0] = umed3(best[0], second[0], k0); best[0] = min(best[0], k0);
+                    second[1] = umed3(best[1], second[1], k1); best[1] = min(best[1], k1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; t++) T[t] = 256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below);
+            }
+        }
+    }
+
+    int accepted = 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        // the two lanes of a query hold the top-2 of disjoint candidate sets: the two smallest keys of the four
+        const uint32_t pb = (uint32_t)__shfl_xor((int)best[t], 32), ps = (uint32_t)__shfl_xor((int)second[t], 32);
+        const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
+        const int qi = qbase + t * 32 + col;
+        if (h == 0 && qi < nA) {
+            const int bd = (int)(b >> 16), sd = (int)(s2 >> 16);
+            const int bidx = bd >= 256 ? -1 : (int)(b & 0xFFFFu);
+            int mm = -1;
+            if (bd <= th && (float)bd < __fmul_rn(ratio, (float)sd)) { mm = bidx; accepted++; }  // :304-308
+            const size_t o = (size_t)p * stride + qi;
+            match[o] = mm;
+            if (WANT_DIST) {
+                if (best_d) best_d[o] = bd;
+                if (second_d) second_d[o] = sd;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
+    if (l == 0 && accepted) atomicAdd(&counts[p], accepted);
+}
+
+// ---- MX-scaled FP4 form ------------------------------------------------------------------------------------------------
+// The same product with the +-1 values as FP4 E2M1 (FrameDev::desc4, 128 B per row) through
+// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0): K = 64 per instruction at the cycles of the bf16 32x32 form, so a
+// tile of 1024 distances is 4 instructions instead of 8, and every staged byte carries two bit positions.  Products are
+// +-1 and the f32 sums are integers of magnitude <= 256: exact.  Lane l supplies bytes [32 s + 16 h, + 16) of row l & 31
+// for k step s (32 values), for A and B alike.  C/D layout and everything after the product as in the int8 form.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int MF4_ROWS = 256;      // candidate rows per LDS stage (32 KB of FP4)
+
+template <bool WANT_DIST, int DIAG>
+__global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__restrict__ table,
+                                                          const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
+                                                          int blocks_per_pair, float ratio, int th, int track_below, int stride,
+                                                          int32_t *__restrict__ match, int32_t *__restrict__ best_d,
+                                                          int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
+    // 16-byte chunk c (of 8) of row r sits at chunk position c ^ ((r >> 1) & 7): two rows share a 256-byte bank span
+    __shared__ v4i tile[MF4_ROWS * 8];
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = bid / blocks_per_pair;
+    const int qb = bid - p * blocks_per_pair;
+    const FrameDev &A = table[fa[p]];
+    const FrameDev &B = table[fb[p]];
+    const int nA = A.n, nB = B.n;
+    if (qb * 256 >= nA) return;        // whole block idle (uniform)
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
+    const int nA8 = max(32, (nA + 31) & ~31), nB8 = (nB + 31) & ~31;
+    const int qbase = qb * 256 + wave * 64;
+
+    v8i bq[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int row = min(qbase + t * 32 + col, nA8 - 1);
+        const v4i *src = reinterpret_cast<const v4i *>(A.desc4) + (size_t)row * 8;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const v4i x = src[2 * s + h];
+            bq[t][s] = (v8i){x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+        }
+    }
+    uint32_t best[2], second[2];
+    float T[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        best[t] = (256u << 16) | 0xFFFFu;
+        second[t] = (256u << 16) | 0xFFFFu;
+        T[t] = (float)(256 - 2 * min(256, track_below));
+    }
+    const int one = 0x7F7F7F7F;        // E8M0 block scale 2^0 in every byte
+
+    const v4i *Bd4 = reinterpret_cast<const v4i *>(B.desc4);
+    for (int c0 = 0; c0 < nB8; c0 += MF4_ROWS) {
+        const int rows = min(MF4_ROWS, nB8 - c0);           // a multiple of 32
+        if (DIAG != 2 || c0 == 0) {
+            // all loads of the stage first, then the LDS writes; loads are unconditional (clamped) so that the array stays
+            // in registers.  (Keeping the next stage's loads in flight during the products costs 32 registers and one wave
+            // per SIMD: measured slower.)
+            v4i stg[MF4_ROWS * 8 / 256];
+#pragma unroll
+            for (int k = 0; k < MF4_ROWS * 8 / 256; k++) stg[k] = Bd4[(size_t)c0 * 8 + min(tid + 256 * k, rows * 8 - 1)];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MF4_ROWS * 8 / 256; k++) {
+                const int i = tid + 256 * k, r = i >> 3, c = i & 7;
+                if (i < rows * 8) tile[r * 8 + (c ^ ((r >> 1) & 7))] = stg[k];
+            }
+            __syncthreads();
+        }
+        for (int rb = 0; rb < rows; rb += 32) {
+            v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+            const v4i *arow = tile + (rb + col) * 8;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const v4i x = arow[(2 * s + h) ^ ((col >> 1) & 7)];
+                const v8i a = {x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0][s], acc0, 4, 4, 0, one, 0, one);
+                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[1][s], acc1, 4, 4, 0, one, 0, one);
+            }
+            float m0 = fmaxf(fmaxf(acc0[0], acc0[1]), acc0[2]), m1 = fmaxf(fmaxf(acc1[0], acc1[1]), acc1[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) {
+                m0 = fmaxf(fmaxf(m0, acc0[r]), acc0[r + 1]);
+                m1 = fmaxf(fmaxf(m1, acc1[r]), acc1[r + 1]);
+            }
+            m0 = fmaxf(m0, acc0[15]); m1 = fmaxf(m1, acc1[15]);
+            if (DIAG == 1) { best[0] += (uint32_t)(int)(m0 + m1); continue; }
+            if (__any(m0 > T[0] || m1 > T[1])) {            // some lane saw dist < its bound: exact update of the tile
+                const int cand0 = c0 + rb + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int cand = cand0 + (r & 3) + 8 * (r >> 2);
+                    const uint32_t k0 = cand < nB ? ((uint32_t)((256 - (int)acc0[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                    const uint32_t k1 = cand < nB ? ((uint32_t)((256 - (int)acc1[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                    second[0] = umed3(best[0], second[0], k0); best[0] = min(best[0], k0);
+                    second[1] = umed3(best[1], second[1], k1); best[1] = min(best[1], k1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; t++) T[t] = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
+            }
+        }
+    }
+
+    int accepted = 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t pb = (uint32_t)__shfl_xor((int)best[t], 32), ps = (uint32_t)__shfl_xor((int)second[t], 32);
+        const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
+        const int qi = qbase + t * 32 + col;
+        if (h == 0 && qi < nA) {
+            const int bd = (int)(b >> 16), sd = (int)(s2 >> 16);
+            const int bidx = bd >= 256 ? -1 : (int)(b & 0xFFFFu);
+            int mm = -1;
+            if (bd <= th && (float)bd < __fmul_rn(ratio, (float)sd)) { mm = bidx; accepted++; }  // :304-308
+            const size_t o = (size_t)p * stride + qi;
+            match[o] = mm;
+            if (WANT_DIST) {
+                if (best_d) best_d[o] = bd;
+                if (second_d) second_d[o] = sd;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
+    if (l == 0 && accepted) atomicAdd(&counts[p], accepted);
+}
+
 int g_bf_variant = 0;
 
 }  // namespace
@@ -226,6 +484,18 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         else HIPCHK(ctx, hipMemsetAsync(counts, 0, (size_t)n_pairs * 4, ctx->stream));
         return ORBM_OK;
     }
+    // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
+    static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
+    // ORBMATCH_BF2NN_KERNEL=valu selects the vector-ALU xor + popcount kernel (no +-1 image of the frames is built)
+    static const bool env_valu = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return e && !strcmp(e, "valu"); }();
+    // 0 = default: the MX-scaled FP4 MFMA form (10); 11 = the vector-ALU kernel; the rest are A/B and diagnostic forms
+    const int variant = g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : 10;
+    if (variant == 9 || variant == 10) {    // MFMA forms: +-1 images of the frames, built on first use (before any staging: it uses the workspace)
+        const int bits = variant == 9 ? 8 : 4;
+        int rc8 = orbm_ensure_image(ctx, bits, io_on_device ? 0 : n_pairs, io_on_device ? nullptr : frame_a);
+        if (!rc8 && !io_on_device) rc8 = orbm_ensure_image(ctx, bits, n_pairs, frame_b);
+        if (rc8) return rc8;
+    }
     const size_t out_elems = (size_t)n_pairs * stride;
     IoStage io(ctx, io_on_device);
     if (!io_on_device) {
@@ -247,10 +517,43 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         for (int t = std::max(th + 1, 1); t <= 256; t++)
             if ((float)th < ratio * (float)t) { track_below = t; break; }
     }
-    // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
-    static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
-    const int variant = (g_bf_variant == 0 && env_early_abandon) ? 8 : g_bf_variant;
-    const int R = (variant == 0 || variant == 3 || variant >= 7 || variant < 0) ? 2 : 4;
+    if (variant == 10) {                // MX-scaled FP4 MFMA form
+        const int bpp9 = (max_na + 255) / 256;
+        const long long grid9 = (long long)n_pairs * bpp9;
+        if (grid9 > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
+        static const int diag10 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
+#define MF4_LAUNCH(WD, DG)                                                                                                       \
+        hipLaunchKernelGGL((bf2nn_mfma4_kernel<WD, DG>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+                           (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
+        if (diag10 == 1) MF4_LAUNCH(false, 1);
+        else if (diag10 == 2) MF4_LAUNCH(false, 2);
+        else if (best_d || second_d) MF4_LAUNCH(true, 0);
+        else MF4_LAUNCH(false, 0);
+#undef MF4_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return io.finish();
+    }
+    if (variant == 9) {                 // MFMA form: +-1 int8 images of the frames, built on first use
+        const int bpp9 = (max_na + 255) / 256;
+        const long long grid9 = (long long)n_pairs * bpp9;
+        if (grid9 > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
+        static const int diag9 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
+        if (diag9 == 1)
+            hipLaunchKernelGGL((bf2nn_mfma_kernel<false, 1>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
+                               (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
+        else if (diag9 == 2)
+            hipLaunchKernelGGL((bf2nn_mfma_kernel<false, 2>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
+                               (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
+        else if (best_d || second_d)
+            hipLaunchKernelGGL((bf2nn_mfma_kernel<true, 0>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
+                               (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
+        else
+            hipLaunchKernelGGL((bf2nn_mfma_kernel<false, 0>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
+                               (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
+        HIPCHK(ctx, hipGetLastError());
+        return io.finish();
+    }
+    const int R = (variant == 3 || variant >= 7 || variant <= 0) ? 2 : 4;
     const int bpp = (max_na + 256 * R - 1) / (256 * R);
     const long long grid = (long long)n_pairs * bpp;
     if (grid > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");

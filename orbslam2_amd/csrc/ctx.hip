@@ -521,8 +521,8 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
             f.sigma2[l] = l < v.n_levels ? v.level_sigma2[l] : 0.f;
         }
         int32_t id;
-        if (!ctx->free_frames.empty()) { id = ctx->free_frames.back(); ctx->free_frames.pop_back(); ctx->h_frames[id] = f; ctx->frame_arena[id] = arena_id; }
-        else { id = (int32_t)ctx->h_frames.size(); ctx->h_frames.push_back(f); ctx->frame_arena.push_back(arena_id); }
+        if (!ctx->free_frames.empty()) { id = ctx->free_frames.back(); ctx->free_frames.pop_back(); ctx->h_frames[id] = f; ctx->frame_arena[id] = arena_id; ctx->frame_arena8[id] = -1; ctx->frame_arena4[id] = -1; }
+        else { id = (int32_t)ctx->h_frames.size(); ctx->h_frames.push_back(f); ctx->frame_arena.push_back(arena_id); ctx->frame_arena8.push_back(-1); ctx->frame_arena4.push_back(-1); }
         out_ids[k] = id;
         lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
     }
@@ -569,6 +569,10 @@ int orbm_frames_free(orbm_ctx *ctx, int n_frames, const int32_t *ids) {
         if (ctx->frame_arena[id] < 0) continue;  // duplicate in the list
         arena_unref(ctx, ctx->frame_arena[id]);
         ctx->frame_arena[id] = -1;
+        arena_unref(ctx, ctx->frame_arena8[id]);
+        ctx->frame_arena8[id] = -1;
+        arena_unref(ctx, ctx->frame_arena4[id]);
+        ctx->frame_arena4[id] = -1;
         ctx->free_frames.push_back(id);
     }
     return ORBM_OK;
@@ -747,3 +751,107 @@ int orbm_popcount_peak(orbm_ctx *ctx, int iters, double *lane_ops_per_s) {
 }
 
 }  // extern "C"
+
+// ---- +-1 images of the descriptors (operands of the MFMA brute-force search) -------------------------------------------
+// BITS = 8: every descriptor bit as one int8 (0 -> +1, 1 -> -1), 256 B per row.  BITS = 4: as FP4 E2M1 (+1.0 = 0x2,
+// -1.0 = 0xA), 128 B per row.  thread = one 16-byte chunk of one output row; rows >= n -> 0 (rows padded to 32).
+template <int BITS>
+__global__ __launch_bounds__(256) void expand_image_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int blocks_per_frame) {
+    constexpr int CHUNKS = BITS == 8 ? 16 : 8;          // 16-byte chunks per output row
+    const int f = blockIdx.x / blocks_per_frame;
+    const FrameDev &F = table[ids[f]];
+    const int row = (blockIdx.x - f * blocks_per_frame) * (256 / CHUNKS) + (int)(threadIdx.x / CHUNKS), chunk = threadIdx.x % CHUNKS;
+    const int n8 = max(32, (F.n + 31) & ~31);
+    if (row >= n8) return;
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (row < F.n) {
+        uint32_t o[4];
+        if (BITS == 8) {
+            const uint32_t w = F.desc[(size_t)row * 8 + (chunk >> 1)];
+            const uint32_t bits = (chunk & 1) ? (w >> 16) : (w & 0xFFFFu);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nib = (bits >> (4 * q)) & 0xFu;
+                const uint32_t b01 = (nib * 0x00204081u) & 0x01010101u;   // bit k of the nibble -> byte k
+                o[q] = 0x01010101u + b01 * 0xFEu;                          // byte 0 -> 0x01 (+1), byte 1 -> 0xFF (-1); no carries
+            }
+        } else {
+            const uint32_t w = F.desc[(size_t)row * 8 + chunk];            // 32 bits -> 32 nibbles = 16 bytes
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t byte = (w >> (8 * q)) & 0xFFu;
+                uint32_t v = 0x22222222u;                                  // +1.0 everywhere
+#pragma unroll
+                for (int j = 0; j < 8; j++) v |= ((byte >> j) & 1u) << (4 * j + 3);   // sign bit of nibble j
+                o[q] = v;
+            }
+        }
+        out = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    uint32_t *base = const_cast<uint32_t *>(BITS == 8 ? F.desc8 : F.desc4);
+    reinterpret_cast<uint4 *>(base)[(size_t)row * CHUNKS + chunk] = out;
+}
+
+int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
+    std::vector<int> &slot_arena = bits == 8 ? ctx->frame_arena8 : ctx->frame_arena4;
+    auto image_of = [bits](FrameDev &f) -> const uint32_t *& { return bits == 8 ? f.desc8 : f.desc4; };
+    const size_t row_bytes = bits == 8 ? 256 : 128;
+    std::vector<int32_t> need;
+    if (ids) {
+        for (int i = 0; i < n; i++) {
+            const int32_t id = ids[i];
+            if (image_of(ctx->h_frames[id]) || slot_arena[id] == -2) continue;
+            slot_arena[id] = -2;                                           // listed (also de-duplicates)
+            need.push_back(id);
+        }
+    } else {
+        for (size_t id = 0; id < ctx->h_frames.size(); id++)
+            if (ctx->frame_arena[id] >= 0 && !image_of(ctx->h_frames[id])) need.push_back((int32_t)id);
+    }
+    if (need.empty()) return ORBM_OK;
+    for (int32_t id : need) slot_arena[id] = -1;
+    size_t total = 0;
+    int max_n8 = 32;
+    std::vector<size_t> off(need.size());
+    for (size_t k = 0; k < need.size(); k++) {
+        const int n8 = std::max(32, (ctx->h_frames[need[k]].n + 31) & ~31);
+        off[k] = total; total += (size_t)n8 * row_bytes;
+        max_n8 = std::max(max_n8, n8);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Arena ar;
+    { int rc = orbm_arena_alloc(ctx, total, &ar); if (rc) return rc; }
+    ar.live = (int)need.size();
+    int arena_id = -1;
+    for (size_t i = 0; i < ctx->arenas.size(); i++) if (!ctx->arenas[i].base) { arena_id = (int)i; break; }
+    if (arena_id < 0) { ctx->arenas.push_back(ar); arena_id = (int)ctx->arenas.size() - 1; } else ctx->arenas[arena_id] = ar;
+    size_t lo = SIZE_MAX, hi = 0;
+    for (size_t k = 0; k < need.size(); k++) {
+        const int32_t id = need[k];
+        image_of(ctx->h_frames[id]) = (const uint32_t *)((char *)ar.base + off[k]);
+        slot_arena[id] = arena_id;
+        lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
+    }
+    int rc = orbm_ws_reserve(ctx, need.size() * 4);
+    if (rc) return rc;
+    const size_t tab_bytes = (hi - lo + 1) * sizeof(FrameDev), id_bytes = need.size() * 4, o_ids = align_up(tab_bytes, 256);
+    if (char *pin = (char *)orbm_pin_up(ctx, o_ids + id_bytes)) {
+        memcpy(pin, ctx->h_frames.data() + lo, tab_bytes);
+        memcpy(pin + o_ids, need.data(), id_bytes);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames + lo, pin, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws, pin + o_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, tab_bytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->ws, need.data(), id_bytes, hipMemcpyHostToDevice));
+    }
+    if (bits == 8) {
+        const int bpf = max_n8 / 16;
+        hipLaunchKernelGGL(expand_image_kernel<8>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+    } else {
+        const int bpf = max_n8 / 32;
+        hipLaunchKernelGGL(expand_image_kernel<4>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // the pinned block and the id list in ws are reused by the caller
+    return ORBM_OK;
+}

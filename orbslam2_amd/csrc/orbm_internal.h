@@ -26,6 +26,11 @@ struct FrameDev {
     // n > 8192.
     uint16_t *cell_nxt;
     const uint32_t *fv_node, *fv_off, *fv_idx;
+    // every descriptor bit as one int8 (+1 for 0, -1 for 1), 256 B per row, rows padded with zeros to a multiple of 32:
+    // the operand image of the MFMA form of the brute-force search.  Built on first use (orbm_ensure_desc8), else null.
+    const uint32_t *desc8;
+    // the same as FP4 (E2M1) values, two per byte: +1.0 = 0x2, -1.0 = 0xA; 128 B per row (operands of the MX-scaled MFMA form)
+    const uint32_t *desc4;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     float sf[ORBM_MAX_LEVELS];
     float sigma2[ORBM_MAX_LEVELS];
@@ -78,6 +83,8 @@ struct orbm_ctx {
     // frame table
     std::vector<FrameDev> h_frames;
     std::vector<int> frame_arena;      // arena index per slot, -1 = free slot
+    std::vector<int> frame_arena8;     // arena of the slot's desc8 image, -1 = none
+    std::vector<int> frame_arena4;     // arena of the slot's desc4 image, -1 = none
     std::vector<int32_t> free_frames;
     FrameDev *d_frames = nullptr;
     size_t d_frames_cap = 0;
@@ -128,6 +135,7 @@ int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
 void *orbm_pin_up(orbm_ctx *ctx, size_t bytes);      // pinned upload staging of at least `bytes`, or null (too large / failed)
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
 int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
+int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // bits = 8 (desc8) or 4 (desc4); ids == nullptr: every live frame
 int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
                        std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);

@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 fa = torch.tensor(ids[pa], dtype=torch.int32, device=dev); fb = torch.tensor(ids[pb], dtype=torch.int32, device=dev)
 match = torch.empty((P, 2000), dtype=torch.int32, device=dev); counts = torch.empty(P, dtype=torch.int32, device=dev)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-names = {0: "R2U4", 1: "R4U2", 2: "R4U1", 3: "R2U2", 4: "R4U2-noupdate", 5: "R4U2-always", 6: "R4U4", 7: "R2U4-trackall", 8: "R2U4-early-abandon"}
+names = {11: "R2U4", 1: "R4U2", 2: "R4U1", 3: "R2U2", 4: "R4U2-noupdate", 5: "R4U2-always", 6: "R4U4", 7: "R2U4-trackall", 8: "R2U4-early-abandon", 9: "MFMA-i8", 10: "MFMA-fp4-mx"}
 res = {v: [] for v in names}
 for rnd in range(5):
     for v in names:
@@ -28,13 +28,13 @@ for rnd in range(5):
         e1.record(); torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1))
 ref = None
-for v in (0, 8):   # the early-abandon variant must give the same matches
+for v in (11, 8, 9, 10):   # the early-abandon and MFMA variants must give the same matches
     L.orbm__bf2nn_variant(v)
     ctx.bf2nn_dev(P, fa.data_ptr(), fb.data_ptr(), 0.75, 50, 2000, match.data_ptr(), None, None, counts.data_ptr())
     torch.cuda.synchronize()
     cur = (match.clone(), counts.clone())
     if ref is None: ref = cur
-    else: print("early-abandon identical to default:", bool((cur[0] == ref[0]).all() and (cur[1] == ref[1]).all()))
+    else: print("variant %d identical to default:" % v, bool((cur[0] == ref[0]).all() and (cur[1] == ref[1]).all()))
 L.orbm__bf2nn_variant(0)
 for v in names:
     t = np.array(res[v][1:])
