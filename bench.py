@@ -27,8 +27,13 @@ N_FEAT = 2000
 STORE_KF = 96
 PAIRS_PER_STEP = 4096
 RATIO, TH = 0.75, 50
-# integer-popcount roofline: per wave64 comparison one SIMD must issue 8 v_xor_b32
-# (2 cycles each) + 8 v_bcnt_u32_b32 (4 cycles each) = 48 cycles; 256 CUs x 4 SIMDs x 64 lanes @ 2.4 GHz
+# The headline kernel computes Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA,
+# DESIGN.md section 4.1): one comparison = a 256-long dot product = 512 FLOP.  Dense FP4 peak: one
+# v_mfma_scale_f32_32x32x64_f8f6f4 (2 * 32 * 32 * 64 FLOP) per 32 cycles per SIMD, 256 CUs x 4 SIMDs @ 2.4 GHz
+FLOP_PER_CMP = 512.0
+PEAK_MFMA_TFLOPS = 256 * 4 * (2 * 32 * 32 * 64 / 32.0) * 2.4e9 / 1e12
+# integer-popcount roofline of the vector-ALU kernel (reported in `extra`): per wave64 comparison one SIMD must issue
+# 8 v_xor_b32 (2 cycles each) + 8 v_bcnt_u32_b32 (4 cycles each) = 48 cycles; 256 CUs x 4 SIMDs x 64 lanes @ 2.4 GHz
 PEAK_TCMPS = 256 * 4 * 64 * 2.4e9 / 48.0 / 1e12
 
 
@@ -116,27 +121,30 @@ def secondary(ctx, torch, dev, kfs, ids):
         ctx.search_bow_dev(1, 8192, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
         e1.record(); torch.cuda.synchronize()
     out["search_bow_kfkf_pairs_per_s"] = round(8192 / (e0.elapsed_time(e1) * 1e-3), 1)
-    # config 2 again with the opt-in early-abandon kernel (ORBMATCH_BF2NN_EARLY_ABANDON=1): identical matches, but the
-    # last 64 bits of a comparison are skipped when the first 192 already reach the tracking bound, so this is NOT the
-    # headline (which evaluates every distance in full); reported as reference-equivalent comparisons per second
+    # config 2 again with the other forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount on the
+    # vector ALU (ORBMATCH_BF2NN_KERNEL=valu; the form the reference's arithmetic maps to directly), the same with early
+    # abandon (ORBMATCH_BF2NN_EARLY_ABANDON=1: the last 64 bits of a comparison are skipped when the first 192 already
+    # reach the tracking bound, so not every distance is evaluated in full), and the int8 MFMA form
     from orbslam2_amd import _lib
     L = _lib.load()
     fa2, fb2 = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
     tfa2 = torch.tensor(fa2, device=dev); tfb2 = torch.tensor(fb2, device=dev)
     m2 = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
-    try:
-        L.orbm__bf2nn_variant(8)
-        best = 1e30
-        for rep in range(4):
-            e0, e1 = ev(), ev(); e0.record()
-            ctx.bf2nn_dev(PAIRS_PER_STEP, tfa2.data_ptr(), tfb2.data_ptr(), RATIO, TH, N_FEAT, m2.data_ptr(), None, None, c2.data_ptr())
-            e1.record(); torch.cuda.synchronize()
-            if rep:
-                best = min(best, e0.elapsed_time(e1))
-    finally:
-        L.orbm__bf2nn_variant(0)
-    out["bf2nn_early_abandon_pairs_per_s"] = round(PAIRS_PER_STEP / (best * 1e-3), 1)
-    out["bf2nn_early_abandon_equivalent_Gcmps"] = round(PAIRS_PER_STEP * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
+    for variant, name in ((11, "valu_popcount"), (8, "valu_early_abandon"), (9, "mfma_int8")):
+        try:
+            L.orbm__bf2nn_variant(variant)
+            best = 1e30
+            for rep in range(4):
+                e0, e1 = ev(), ev(); e0.record()
+                ctx.bf2nn_dev(PAIRS_PER_STEP, tfa2.data_ptr(), tfb2.data_ptr(), RATIO, TH, N_FEAT, m2.data_ptr(), None, None, c2.data_ptr())
+                e1.record(); torch.cuda.synchronize()
+                if rep:
+                    best = min(best, e0.elapsed_time(e1))
+        finally:
+            L.orbm__bf2nn_variant(0)
+        out[f"bf2nn_{name}_pairs_per_s"] = round(PAIRS_PER_STEP / (best * 1e-3), 1)
+        out[f"bf2nn_{name}_Gcmps"] = round(PAIRS_PER_STEP * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
+    out["bf2nn_valu_popcount_frac_of_popcount_peak"] = round(out["bf2nn_valu_popcount_Gcmps"] / 1e3 / PEAK_TCMPS, 4)
     # config 4 as stated: ONE frame against 64 candidate keyframes (relocalisation / loop closure), SearchByBoW(KF, F)
     cand = ids[rng.choice(len(ids), 64, replace=False)].astype(np.int32)
     tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(64, ids[0], np.int32), device=dev)
@@ -316,7 +324,8 @@ def main():
     cmps_per_launch = float(P) * N_FEAT * N_FEAT
     total_cmps = cmps_per_launch * args.steps * world
     if rank == 0:
-        achieved = cmps_per_launch / (kms * 1e-3) / 1e12
+        achieved_tcmps = cmps_per_launch / (kms * 1e-3) / 1e12
+        achieved = achieved_tcmps * FLOP_PER_CMP
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_bf2nn_traffic.json")
         if os.path.exists(tj):
@@ -331,19 +340,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "fp4-mx (+-1 per descriptor bit, exact) x fp4-mx -> f32 accumulate (exact integers)", "data": "synthetic",
             "config": {"workload": "brute-force 2-NN Hamming + TH_LOW + ratio test, 2000x2000 256-bit descriptors per keyframe pair "
                                    "(BASELINE configs[1]), batched", "pairs_per_step_per_gpu": P, "store_keyframes": STORE_KF,
                        "features_per_keyframe": N_FEAT, "ratio": RATIO, "th": TH,
                        "parallelism": f"pairs sharded over {world} rank(s), RCCL gather of match lists to rank 0" if world > 1 else "1 GPU"},
             "pairs_per_s": round(P * args.steps * world / dt, 1),
-            "roofline": {"bound": "valu-int-popcount", "achieved": round(achieved, 4), "peak": round(PEAK_TCMPS, 4),
-                         "unit": "T Hamming cmps/s", "frac": round(achieved / PEAK_TCMPS, 4), "traffic": traffic,
-                         "kernel": "bf2nn_kernel<2,4,0>", "kernel_ms": round(kms, 4),
-                         "lane_ops_per_cmp": 16, "achieved_tlane_ops": round(achieved * 16, 2),
-                         "note": "peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cyc + 8 bcnt x 4 cyc); "
-                                 "BASELINE.md's simpler 39.3 T lane-op/s / 16 = 2.458 T cmps/s gives frac "
-                                 f"{achieved / 2.4576:.3f}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_MFMA_TFLOPS, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "bf2nn_mfma4_kernel<false,0>", "kernel_ms": round(kms, 4),
+                         "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
+                         "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
+                                 "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz; "
+                                 "the chip holds about 1.5-1.7 GHz in MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back)"},
         }
         if not args.no_extra:
             try:

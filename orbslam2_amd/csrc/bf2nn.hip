@@ -329,13 +329,15 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
 // ---- MX-scaled FP4 form ------------------------------------------------------------------------------------------------
 // The same product with the +-1 values as FP4 E2M1 (FrameDev::desc4, 128 B per row) through
 // v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0): K = 64 per instruction at the cycles of the bf16 32x32 form, so a
-// tile of 1024 distances is 4 instructions instead of 8, and every staged byte carries two bit positions.  Products are
+// tile of 1024 distances is 4 instructions instead of 8, and every staged byte carries two bit positions.  (The 16x16x128
+// shape of the same instruction was measured 12 % slower here, 8-wave workgroups and register-prefetched stages no
+// faster.)  Products are
 // +-1 and the f32 sums are integers of magnitude <= 256: exact.  Lane l supplies bytes [32 s + 16 h, + 16) of row l & 31
 // for k step s (32 values), for A and B alike.  C/D layout and everything after the product as in the int8 form.
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int MF4_ROWS = 256;      // candidate rows per LDS stage (32 KB of FP4)
+constexpr int MF4_ROWS = 256;      // candidate rows in LDS (32 KB of FP4), two buffers of half of it
 
 template <bool WANT_DIST, int DIAG>
 __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__restrict__ table,
@@ -378,26 +380,33 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     const int one = 0x7F7F7F7F;        // E8M0 block scale 2^0 in every byte
 
     const v4i *Bd4 = reinterpret_cast<const v4i *>(B.desc4);
-    for (int c0 = 0; c0 < nB8; c0 += MF4_ROWS) {
-        const int rows = min(MF4_ROWS, nB8 - c0);           // a multiple of 32
-        if (DIAG != 2 || c0 == 0) {
-            // all loads of the stage first, then the LDS writes; loads are unconditional (clamped) so that the array stays
-            // in registers.  (Keeping the next stage's loads in flight during the products costs 32 registers and one wave
-            // per SIMD: measured slower.)
-            v4i stg[MF4_ROWS * 8 / 256];
+    // Two LDS buffers of MF4_ROWS / 2 rows; the next stage travels global -> LDS directly (global_load_lds, no registers)
+    // while the current one is multiplied; one barrier per stage.  A wave instruction fills 1 KB = 8 rows of LDS in lane
+    // order, so the swizzle is applied to the global address each lane reads: LDS chunk position (r, cpos) holds chunk
+    // cpos ^ ((r >> 1) & 7) of row r.  Rows past the end of the frame image are clamped (never multiplied).
+    constexpr int HALF = MF4_ROWS / 2;                      // rows per buffer
+    constexpr int INSTR_PER_WAVE = HALF * 8 / 256;          // 16-byte chunks per buffer / (4 waves x 64 lanes)
+    auto issue_stage = [&](int c0, int buf) {
 #pragma unroll
-            for (int k = 0; k < MF4_ROWS * 8 / 256; k++) stg[k] = Bd4[(size_t)c0 * 8 + min(tid + 256 * k, rows * 8 - 1)];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < MF4_ROWS * 8 / 256; k++) {
-                const int i = tid + 256 * k, r = i >> 3, c = i & 7;
-                if (i < rows * 8) tile[r * 8 + (c ^ ((r >> 1) & 7))] = stg[k];
-            }
-            __syncthreads();
+        for (int j = 0; j < INSTR_PER_WAVE; j++) {
+            const int g0 = __builtin_amdgcn_readfirstlane((wave * INSTR_PER_WAVE + j) * 64);
+            const int g = g0 + l, r = g >> 3, cpos = g & 7;
+            const int row = min(c0 + r, nB8 - 1);
+            const v4i *src = Bd4 + (size_t)row * 8 + (cpos ^ ((r >> 1) & 7));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(tile + buf * (HALF * 8) + g0), 16, 0, 0);
         }
+    };
+    if (nB8 > 0) issue_stage(0, 0);
+    int stage = 0;
+    for (int c0 = 0; c0 < nB8; c0 += HALF, stage ^= 1) {
+        const int rows = min(HALF, nB8 - c0);               // a multiple of 32
+        __syncthreads();                                    // stage `stage` has landed (vmcnt(0) precedes the barrier); the other buffer is free
+        if (DIAG != 2 && c0 + HALF < nB8) issue_stage(c0 + HALF, stage ^ 1);
+        const v4i *tbuf = tile + (DIAG == 2 ? 0 : stage) * (HALF * 8);
         for (int rb = 0; rb < rows; rb += 32) {
             v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-            const v4i *arow = tile + (rb + col) * 8;
+            const v4i *arow = tbuf + (rb + col) * 8;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const v4i x = arow[(2 * s + h) ^ ((col >> 1) & 7)];

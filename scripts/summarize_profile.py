@@ -9,7 +9,8 @@ with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-def counters(sub, kern="bf2nn"):
+HEAD = "bf2nn_mfma4"      # the headline kernel (bench.py also runs the other forms once each, in `extra`)
+def counters(sub, kern=HEAD):
     f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -17,21 +18,23 @@ def counters(sub, kern="bf2nn"):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 fetch, nf = counters("fetch"); write, _ = counters("write"); sq, _ = counters("sq")
-try:
-    sq2, _ = counters("sq2"); sq.update(sq2)
-except Exception:
-    pass
-bf = [r for r in rows if "bf2nn" in r["Name"]][0]
+for extra_pass in ("sq2", "sq3"):
+    try:
+        more, _ = counters(extra_pass); sq.update(more)
+    except Exception:
+        pass
+bf = [r for r in rows if HEAD in r["Name"]][0]
 P, N = 4096, 2000
-alg_bytes = P * (2 * N * 32 + N * 4 + 4)      # both descriptor sets once per pair + match row + count
+alg_bytes = P * (2 * N * 128 + N * 4 + 4)     # both +-1 FP4 images (128 B per descriptor) once per pair + match row + count
 # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # 16-byte-per-lane coalesced reads (our staging and query loads) -> doubled
 hbm = (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024
 summ = {"tag": tag, "kernel": bf["Name"][:80], "launches_profiled": int(bf["Calls"]), "avg_kernel_ns": float(bf["AverageNs"]),
         "cmps_per_launch": P * N * N, "achieved_Tcmps": P * N * N / float(bf["AverageNs"]) / 1e3,
+        "achieved_TFLOPs": P * N * N * 512 / float(bf["AverageNs"]) / 1e3,
         "FETCH_SIZE_KiB_raw": fetch["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": write["WRITE_SIZE"],
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg_bytes, "sq": sq,
-        "valu_insts_per_wave_cmp": sq.get("SQ_INSTS_VALU", 0) / (P * 2048 / 64 * N) if sq else None,
+        "valu_insts_per_tile_of_1024_cmps": sq.get("SQ_INSTS_VALU", 0) / (P * N * N / 1024.0) if sq else None,
         "clock_ghz_est": sq.get("GRBM_GUI_ACTIVE", 0) / 8 / float(bf["AverageNs"]) if sq else None}
 # secondary kernels (bench.py `extra`): windowed SearchByProjection (256 x 50k queries, then one instance alone; two
 # kernels per call: collect_kernel + window_kernel) and SearchByBoW (8192 pairs)
