@@ -228,7 +228,10 @@ int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_
  * strict-< best / second-best update of ORBmatcher.cc:290-300, accept iff best <= th and
  * (float)best < ratio*(float)second (ORBmatcher.cc:304-308).
  * match[p*stride+i] = j or -1; best_d / second_d (nullable) get the raw distances (256 = none);
- * counts[p] = accepted rows.  stride >= max n of the a-frames. */
+ * counts[p] = accepted rows.  stride >= max n of the a-frames.
+ * The distances are computed on the matrix cores from a +-1 image of each frame (128 B per descriptor, built on the
+ * device the first time a frame is used here and released with the frame); results are identical to the xor + popcount
+ * form, which the environment variable ORBMATCH_BF2NN_KERNEL=valu selects instead. */
 int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                      float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
                      int32_t *second_d, int32_t *counts, int io_on_device);
