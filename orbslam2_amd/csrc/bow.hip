@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     __shared__ uint32_t claimed[MAX_N / 32];  // bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint4 s_rows[4][2 * BOWQ_STAGE];   // per wave: the candidate rows of the nodes it is working on
     __shared__ uint32_t s_meta[4][BOWQ_STAGE];    // keypoint index | mp_flags << 16 of each staged candidate
+    __shared__ uint32_t s_pos[4][2];              // per wave: bit per query position still to finalise
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     __syncthreads();
     uint4 *w_rows = s_rows[wave];
     uint32_t *w_meta = s_meta[wave];
+    uint32_t *w_pos = s_pos[wave];
 
     const float *angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -332,6 +334,22 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                 offB = B.fv_off[ib]; nB = B.fv_off[ib + 1] - offB;
                 if (nB == 0) nA = 0;
             }
+        }
+        // Nodes are independent (a keypoint belongs to one node), so their order is free: sorted by candidate count,
+        // the nodes packed into one group of 64 lanes have similar scan lengths (bitonic sort over the wave, descending).
+        {
+            uint32_t key = ((nA ? 0xFFFFu - min(nB, 0xFFFFu) : 0xFFFFu) << 6) | (uint32_t)lane;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)key, j, 64);
+                    const bool asc = (lane & k) == 0, lower = (lane & j) == 0;
+                    key = (lower == asc) ? min(key, other) : max(key, other);
+                }
+            const int from = (int)(key & 63u);
+            nA = (uint32_t)__shfl((int)nA, from, 64); nB = (uint32_t)__shfl((int)nB, from, 64);
+            offA = (uint32_t)__shfl((int)offA, from, 64); offB = (uint32_t)__shfl((int)offB, from, 64);
         }
         int node = 0;                 // next node (a lane of this batch) with queries left
         uint32_t node_done = 0;       // its queries already handled (nodes with more than 64 queries span groups)
@@ -489,9 +507,19 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
             }
             // ---- finalise in query order inside each node.  A best distance above the threshold can only get worse.
             if ((best >> 16) > thr) qvalid = false;
-            const int smax = wave_max(qvalid ? my_s + 1 : 0);
-            for (int s2 = 0; s2 < smax; s2++) {
-                if (!__any(qvalid && my_s == s2)) continue;       // nobody left at this position (most queries have no plausible match)
+            // positions (rank of a query inside its node) that still hold a query: most queries have no plausible match,
+            // so the set is sparse; it is collected in a per-wave LDS word pair and walked bit by bit
+            if (lane < 2) w_pos[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (qvalid) atomicOr(&w_pos[my_s >> 5], 1u << (my_s & 31));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long positions = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w_pos[0]) |
+                                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w_pos[1]) << 32);
+            while (positions) {
+                const int s2 = __ffsll((long long)positions) - 1;
+                positions &= positions - 1;
                 if (qvalid && my_s == s2) {
                     int ib1 = candidate_index(best & 0xFFFFu);
                     bool stale = (claimed[ib1 >> 5] >> (ib1 & 31)) & 1u;
