@@ -338,8 +338,9 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MF4_ROWS = 256;      // candidate rows in LDS (32 KB of FP4), two buffers of half of it
+constexpr int MF4_NT = 2;          // query tiles (of 32) per wave (4 was measured no faster and wastes more on small frames)
 
-template <bool WANT_DIST, int DIAG>
+template <bool WANT_DIST, int DIAG, int NT>
 __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__restrict__ table,
                                                           const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
                                                           int blocks_per_pair, float ratio, int th, int track_below, int stride,
@@ -353,14 +354,15 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     const FrameDev &A = table[fa[p]];
     const FrameDev &B = table[fb[p]];
     const int nA = A.n, nB = B.n;
-    if (qb * 256 >= nA) return;        // whole block idle (uniform)
+    constexpr int QW = 32 * NT;        // queries per wave: NT tiles of 32
+    if (qb * (4 * QW) >= nA) return;   // whole block idle (uniform)
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
     const int nA8 = max(32, (nA + 31) & ~31), nB8 = (nB + 31) & ~31;
-    const int qbase = qb * 256 + wave * 64;
+    const int qbase = qb * (4 * QW) + wave * QW;
 
-    v8i bq[2][4];
+    v8i bq[NT][4];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NT; t++) {
         const int row = min(qbase + t * 32 + col, nA8 - 1);
         const v4i *src = reinterpret_cast<const v4i *>(A.desc4) + (size_t)row * 8;
 #pragma unroll
@@ -369,10 +371,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
             bq[t][s] = (v8i){x[0], x[1], x[2], x[3], 0, 0, 0, 0};
         }
     }
-    uint32_t best[2], second[2];
-    float T[2];
+    uint32_t best[NT], second[NT];
+    float T[NT];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NT; t++) {
         best[t] = (256u << 16) | 0xFFFFu;
         second[t] = (256u << 16) | 0xFFFFu;
         T[t] = (float)(256 - 2 * min(256, track_below));
@@ -405,42 +407,49 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
         if (DIAG != 2 && c0 + HALF < nB8) issue_stage(c0 + HALF, stage ^ 1);
         const v4i *tbuf = tile + (DIAG == 2 ? 0 : stage) * (HALF * 8);
         for (int rb = 0; rb < rows; rb += 32) {
-            v16f acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+            v16f acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const v4i *arow = tbuf + (rb + col) * 8;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const v4i x = arow[(2 * s + h) ^ ((col >> 1) & 7)];
                 const v8i a = {x[0], x[1], x[2], x[3], 0, 0, 0, 0};
-                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0][s], acc0, 4, 4, 0, one, 0, one);
-                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[1][s], acc1, 4, 4, 0, one, 0, one);
-            }
-            float m0 = fmaxf(fmaxf(acc0[0], acc0[1]), acc0[2]), m1 = fmaxf(fmaxf(acc1[0], acc1[1]), acc1[2]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) {
-                m0 = fmaxf(fmaxf(m0, acc0[r]), acc0[r + 1]);
-                m1 = fmaxf(fmaxf(m1, acc1[r]), acc1[r + 1]);
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one);
             }
-            m0 = fmaxf(m0, acc0[15]); m1 = fmaxf(m1, acc1[15]);
-            if (DIAG == 1) { best[0] += (uint32_t)(int)(m0 + m1); continue; }
-            if (__any(m0 > T[0] || m1 > T[1])) {            // some lane saw dist < its bound: exact update of the tile
+            bool fire = false;
+            float msum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float m = fmaxf(fmaxf(acc[t][0], acc[t][1]), acc[t][2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[t][r]), acc[t][r + 1]);
+                m = fmaxf(m, acc[t][15]);
+                fire = fire || m > T[t];
+                msum += m;
+            }
+            if (DIAG == 1) { best[0] += (uint32_t)(int)msum; continue; }
+            if (__any(fire)) {                              // some lane saw dist < its bound: exact update of the step
                 const int cand0 = c0 + rb + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int cand = cand0 + (r & 3) + 8 * (r >> 2);
-                    const uint32_t k0 = cand < nB ? ((uint32_t)((256 - (int)acc0[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
-                    const uint32_t k1 = cand < nB ? ((uint32_t)((256 - (int)acc1[r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
-                    second[0] = umed3(best[0], second[0], k0); best[0] = min(best[0], k0);
-                    second[1] = umed3(best[1], second[1], k1); best[1] = min(best[1], k1);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const uint32_t key = cand < nB ? ((uint32_t)((256 - (int)acc[t][r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                        second[t] = umed3(best[t], second[t], key); best[t] = min(best[t], key);
+                    }
                 }
 #pragma unroll
-                for (int t = 0; t < 2; t++) T[t] = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
+                for (int t = 0; t < NT; t++) T[t] = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
             }
         }
     }
 
     int accepted = 0;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NT; t++) {
         const uint32_t pb = (uint32_t)__shfl_xor((int)best[t], 32), ps = (uint32_t)__shfl_xor((int)second[t], 32);
         const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
         const int qi = qbase + t * 32 + col;
@@ -527,12 +536,13 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
             if ((float)th < ratio * (float)t) { track_below = t; break; }
     }
     if (variant == 10) {                // MX-scaled FP4 MFMA form
-        const int bpp9 = (max_na + 255) / 256;
+        const int per_block = 4 * 32 * MF4_NT;
+        const int bpp9 = (max_na + per_block - 1) / per_block;
         const long long grid9 = (long long)n_pairs * bpp9;
         if (grid9 > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
         static const int diag10 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
 #define MF4_LAUNCH(WD, DG)                                                                                                       \
-        hipLaunchKernelGGL((bf2nn_mfma4_kernel<WD, DG>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+        hipLaunchKernelGGL((bf2nn_mfma4_kernel<WD, DG, MF4_NT>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
         if (diag10 == 1) MF4_LAUNCH(false, 1);
         else if (diag10 == 2) MF4_LAUNCH(false, 2);
