@@ -53,3 +53,38 @@ def test_bad_arguments_are_refused_and_context_survives(ctx, orc):
     wc, wm, wb, ws, _ = orc.bf2nn(kfs[0], kfs[0], 0.75, 50)
     assert c[0] == wc and np.array_equal(m[0], wm)
     ctx.free_frames([ids[0]]); ctx.free_queries(pid); ctx.free_queries(wid)
+
+
+@pytest.mark.gpu
+def test_no_device_memory_growth_over_upload_match_free_cycles(ctx, orc):
+    """300 cycles of upload -> brute-force match (builds the +-1 images) -> ComputeBoW with BowVectors -> score -> free
+    must not grow the device footprint: arenas, images, BowVector arenas and table slots are all recycled.  (A leak of
+    one cycle's 6 MB would show as 1.8 GB; released arenas may stay pooled, bounded at 256 MB.)"""
+    import torch
+    from orbslam2_amd import synth
+    vocab = synth.make_vocabulary(seed=3, k=6, depth=3)
+    vid = ctx.upload_vocabulary(vocab)
+    rng = np.random.default_rng(4)
+    lm = synth.random_descriptors(rng, 3000)
+    frames = [synth.make_frame(rng, lm, rng.integers(0, 3000, 1500), with_fv=False) for _ in range(6)]
+
+    def cycle():
+        ids = ctx.upload_frames(frames)
+        counts, match, _, _ = ctx.bf2nn(ids[:3], ids[3:], 0.75, 50, stride=1500, want_dist=False)
+        (bv,) = ctx.compute_bow(vid, ids, 4, want_ids=False, want_bowvecs=True)
+        score, _ = ctx.bow_score(bv[:3], bv[3:])
+        ctx.free_bowvecs(bv)
+        ctx.free_frames(ids)
+        return int(counts.sum()), float(score.sum())
+
+    first = cycle()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(300):
+        assert cycle() == first
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    ctx.free_vocabulary(vid)
+    assert free0 - free1 < 300 * 1024 * 1024, (free0, free1)
