@@ -7,13 +7,17 @@
 //
 // The row table is not materialised: membership is two integer compares, so every left keypoint (one per lane)
 // scans ALL right keypoints, staged through LDS 256 at a time and read as broadcasts, in ascending index order.
+// The gates come first and the distance is only computed when some lane of the wave passes them.  Workgroups of one
+// wave (64 left keypoints) when the batch is small -- a single stereo pair, the per-frame case, then spreads over 32
+// workgroups -- and of four waves, which share the staging of the right keypoints, when the batch fills the chip.
 #include "orbm_internal.h"
 
 namespace {
 
 constexpr int ST_TILE = 256;
 
-__global__ __launch_bounds__(256) void stereo_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fl,
+template <int ST_THREADS>
+__global__ __launch_bounds__(ST_THREADS) void stereo_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fl,
                                                      const int32_t *__restrict__ fr, const float *__restrict__ max_d,
                                                      int blocks_per_pair, int stride, int32_t *__restrict__ best_idx,
                                                      int32_t *__restrict__ best_dist) {
@@ -21,7 +25,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(const FrameDev *__restrict_
     __shared__ float s_x[ST_TILE];
     __shared__ int s_minr[ST_TILE], s_maxr[ST_TILE], s_oct[ST_TILE];
     const int p = blockIdx.x / blocks_per_pair;
-    const int iL = (blockIdx.x - p * blocks_per_pair) * 256 + (int)threadIdx.x;
+    const int iL = (blockIdx.x - p * blocks_per_pair) * ST_THREADS + (int)threadIdx.x;
     const FrameDev &L = table[fl[p]];
     const FrameDev &R = table[fr[p]];
     const int tid = threadIdx.x;
@@ -43,29 +47,32 @@ __global__ __launch_bounds__(256) void stereo_kernel(const FrameDev *__restrict_
     int bestDist = ORBM_TH_HIGH, bestIdxR = -1;               // :696
     for (int base = 0; base < R.n; base += ST_TILE) {
         __syncthreads();
-        const int j = base + tid;
-        if (j < R.n) {
-            const uint4 *g = reinterpret_cast<const uint4 *>(R.desc) + 2 * (size_t)j;
-            s_desc[2 * tid] = g[0]; s_desc[2 * tid + 1] = g[1];
-            const float kpY = R.y[j];
-            const int o = R.octave[j];
-            const float r = __fmul_rn(2.0f, R.sf[o]);         // :654
-            s_x[tid] = R.x[j];
-            s_maxr[tid] = (int)ceilf(__fadd_rn(kpY, r));      // :655
-            s_minr[tid] = (int)floorf(__fsub_rn(kpY, r));     // :656
-            s_oct[tid] = o;
+        for (int t = tid; t < ST_TILE; t += ST_THREADS) {
+            const int j = base + t;
+            if (j < R.n) {
+                const uint4 *g = reinterpret_cast<const uint4 *>(R.desc) + 2 * (size_t)j;
+                s_desc[2 * t] = g[0]; s_desc[2 * t + 1] = g[1];
+                const float kpY = R.y[j];
+                const int o = R.octave[j];
+                const float r = __fmul_rn(2.0f, R.sf[o]);         // :654
+                s_x[t] = R.x[j];
+                s_maxr[t] = (int)ceilf(__fadd_rn(kpY, r));        // :655
+                s_minr[t] = (int)floorf(__fsub_rn(kpY, r));       // :656
+                s_oct[t] = o;
+            }
         }
         __syncthreads();
         const int cnt = min(ST_TILE, R.n - base);
         for (int c = 0; c < cnt; c++) {
-            const uint4 lo = s_desc[2 * c], hi = s_desc[2 * c + 1];
-            const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            const int dist = (int)hamming256(q, cd);
             const float uR = s_x[c];
             const int o = s_oct[c];
             const bool ok = live && row >= s_minr[c] && row <= s_maxr[c] &&          // row band (:658-659)
                             !(o < levelL - 1 || o > levelL + 1) &&                     // :712
                             uR >= minU && uR <= uL;                                    // :717
+            if (!__any(ok)) continue;                                                  // wave-uniform
+            const uint4 lo = s_desc[2 * c], hi = s_desc[2 * c + 1];
+            const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int dist = (int)hamming256(q, cd);
             if (ok && dist < bestDist) { bestDist = dist; bestIdxR = base + c; }      // :722-726
         }
     }
@@ -103,10 +110,15 @@ extern "C" int orbm_stereo_match_batch(orbm_ctx *ctx, int n_pairs, const int32_t
         (rc = io.in(max_disparity, (size_t)n_pairs * 4, &dm)) || (rc = io.out(best_idx_r, out_elems * 4, &di)) ||
         (rc = io.out(best_dist, out_elems * 4, &dd)))
         return rc;
-    const int blocks_per_pair = (stride + 255) / 256;
-    hipLaunchKernelGGL(stereo_kernel, dim3((unsigned)(n_pairs * blocks_per_pair)), dim3(256), 0, ctx->stream, ctx->d_frames,
-                       (const int32_t *)dl, (const int32_t *)dr, (const float *)dm, blocks_per_pair, stride, (int32_t *)di,
-                       (int32_t *)dd);
+    if ((long long)n_pairs * ((stride + 255) / 256) < 1024) {
+        const int blocks_per_pair = (stride + 63) / 64;
+        hipLaunchKernelGGL(stereo_kernel<64>, dim3((unsigned)(n_pairs * blocks_per_pair)), dim3(64), 0, ctx->stream, ctx->d_frames,
+                           (const int32_t *)dl, (const int32_t *)dr, (const float *)dm, blocks_per_pair, stride, (int32_t *)di, (int32_t *)dd);
+    } else {
+        const int blocks_per_pair = (stride + 255) / 256;
+        hipLaunchKernelGGL(stereo_kernel<256>, dim3((unsigned)(n_pairs * blocks_per_pair)), dim3(256), 0, ctx->stream, ctx->d_frames,
+                           (const int32_t *)dl, (const int32_t *)dr, (const float *)dm, blocks_per_pair, stride, (int32_t *)di, (int32_t *)dd);
+    }
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }

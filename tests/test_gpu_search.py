@@ -396,6 +396,10 @@ def test_stereo_match_parity(ctx, orc):
         assert np.array_equal(dist[k, :l.n], wd), k
         nmatch += int((wd < 75).sum())
     assert nmatch > 800
+    # a batch large enough for the four-wave form of the kernel (the small batch above runs the one-wave form)
+    rep = 200
+    big_i, big_d = ctx.stereo_match(np.tile(ids[0::2], rep), np.tile(ids[1::2], rep), np.tile(md, rep), stride=1500)
+    assert np.array_equal(big_i, np.tile(idx, (rep, 1))) and np.array_equal(big_d, np.tile(dist, (rep, 1)))
     ctx.free_frames(ids)
 
 
