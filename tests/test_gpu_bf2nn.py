@@ -203,3 +203,37 @@ def test_bf2nn_bench_size_properties(ctx, orc):
         wc, wm, wbd, wsd, _ = orc.bf2nn(kfs[pa[p]], kfs[pb[p]], 0.75, 50)
         assert counts[p] == wc and np.array_equal(match[p], wm) and np.array_equal(bd[p], wbd) and np.array_equal(sd[p], wsd)
     ctx.free_frames(ids)
+
+
+def test_bf2nn_every_distance_value_is_exact(ctx, orc):
+    """Every Hamming distance 0..256 through the matrix-core form (distance = (256 - dot) / 2 of +-1 images): for each d a
+    pair whose candidates sit at exactly d, min(d + 3, 256) and 256 bits from the query (bit positions chosen at random,
+    so every k step of the product takes part); best / second come back as exactly those values, and the accept decision
+    flips where the reference's does (th = d, th = d - 1; the ratio boundary)."""
+    rng = np.random.default_rng(123)
+    frames, want = [], []
+    for d in range(257):
+        q = synth.random_descriptors(rng, 1)
+        def at(dist):
+            bits = np.unpackbits(q[0]).copy()
+            flip = rng.permutation(256)[:dist]
+            bits[flip] ^= 1
+            return np.packbits(bits)
+        d2 = min(d + 3, 256)
+        cands = np.stack([at(256), at(d2), at(d), at(d2)])       # best at index 2; the second-best value appears twice
+        frames.append(synth.make_frame(rng, q, np.arange(1), with_fv=False, p_flip=0.0))
+        frames.append(synth.make_frame(rng, cands, np.arange(4), with_fv=False, p_flip=0.0))
+        want.append((d, d2))
+    ids = ctx.upload_frames(frames)
+    fa, fb = ids[0::2], ids[1::2]
+    for ratio, th in ((0.75, 50), (1.0, 256), (0.99, 100), (2.0, 0)):
+        counts, match, bd, sd = ctx.bf2nn(fa, fb, ratio, th, stride=1)
+        c2, m2, _, _ = ctx.bf2nn(fa, fb, ratio, th, stride=1, want_dist=False)
+        assert np.array_equal(counts, c2) and np.array_equal(match, m2)
+        for d, (wb, ws) in enumerate(want):
+            assert (bd[d, 0], sd[d, 0]) == (wb, ws), (d, bd[d, 0], sd[d, 0])
+            accept = wb <= th and np.float32(wb) < np.float32(ratio) * np.float32(ws)
+            assert match[d, 0] == (2 if accept else -1) and counts[d] == int(accept), (ratio, th, d)
+            wc, wm, wbd, wsd, _ = orc.bf2nn(frames[2 * d], frames[2 * d + 1], ratio, th)
+            assert wc == counts[d] and wm[0] == match[d, 0] and wbd[0] == wb and wsd[0] == ws
+    ctx.free_frames(ids)
