@@ -206,7 +206,7 @@ int orbm_frame_fv_download(orbm_ctx *ctx, int32_t frame, int32_t *n_nodes, uint3
  *   best_dist[p*stride+iL] = least Hamming distance below TH_HIGH (100 when none), best_idx_r[...] = that right
  *   keypoint or -1; candidates = right keypoints whose row band [floor(y-2*sf), ceil(y+2*sf)] holds row (int)vL,
  *   octave within +-1, uL - max_disparity <= uR <= uL, ascending index, strict '<'.
- * Rows beyond stride / left n are untouched.  The caller continues with :734 (SAD refinement) where
+ * Entries between the left frame's n and stride are written as no match (-1, 100).  The caller continues with :734 (SAD refinement) where
  * best_dist < (TH_HIGH+TH_LOW)/2.  Row bands reaching outside the image are undefined behaviour in the reference;
  * here they simply never match a row that does not exist. */
 int orbm_stereo_match_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_left, const int32_t *frame_right,

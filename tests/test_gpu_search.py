@@ -396,10 +396,38 @@ def test_stereo_match_parity(ctx, orc):
         assert np.array_equal(dist[k, :l.n], wd), k
         nmatch += int((wd < 75).sum())
     assert nmatch > 800
-    # a batch large enough for the four-wave form of the kernel (the small batch above runs the one-wave form)
+    # a batch large enough for the four-wave form of the kernels (the small batch above runs the one-wave form), and
+    # the scan form (used for right frames above 4096 keypoints) next to the row-binned one
+    from orbslam2_amd import _lib
     rep = 200
-    big_i, big_d = ctx.stereo_match(np.tile(ids[0::2], rep), np.tile(ids[1::2], rep), np.tile(md, rep), stride=1500)
-    assert np.array_equal(big_i, np.tile(idx, (rep, 1))) and np.array_equal(big_d, np.tile(dist, (rep, 1)))
+    for scan_form in (0, 1):
+        _lib.load().orbm__stereo_variant(scan_form)
+        try:
+            i2, d2 = ctx.stereo_match(ids[0::2], ids[1::2], md, stride=1500)
+            big_i, big_d = ctx.stereo_match(np.tile(ids[0::2], rep), np.tile(ids[1::2], rep), np.tile(md, rep), stride=1500)
+        finally:
+            _lib.load().orbm__stereo_variant(0)
+        assert np.array_equal(i2, idx) and np.array_equal(d2, dist), scan_form
+        assert np.array_equal(big_i, np.tile(idx, (rep, 1))) and np.array_equal(big_d, np.tile(dist, (rep, 1))), scan_form
+    ctx.free_frames(ids)
+    # rows at the edges of the row bins (bands reaching below row 0, rows beyond the 2048 bins) and a right frame above
+    # the 4096 keypoints the in-LDS sort holds (scan form chosen by the library)
+    edge = []
+    for n, ylo, yhi in ((400, 0.0, 9.0), (400, 2030.0, 2075.0), (5000, 16.0, 464.0)):
+        lm = synth.random_descriptors(rng, n)
+        xl = rng.uniform(16, 624, n).astype(np.float32); yl = rng.uniform(ylo, yhi, n).astype(np.float32)
+        l = synth.make_frame(rng, lm, np.arange(n), x=xl, y=yl, with_fv=False, bounds=(0.0, 0.0, 640.0, 2100.0))
+        perm = rng.permutation(n)
+        r = synth.make_frame(rng, lm, perm, x=(xl - rng.uniform(0, 40, n).astype(np.float32))[perm],
+                             y=(yl + rng.normal(0, 1.5, n).astype(np.float32))[perm], octave=l.octave[perm], with_fv=False,
+                             bounds=(0.0, 0.0, 640.0, 2100.0))
+        edge.append((l, r))
+    ids = ctx.upload_frames([f for pr in edge for f in pr])
+    idx, dist = ctx.stereo_match(ids[0::2], ids[1::2], np.full(3, 45.0, np.float32), stride=5000)
+    for k, (l, r) in enumerate(edge):
+        wi, wd, _ = orc.stereo_match(l, r, 4096, 45.0)
+        assert np.array_equal(idx[k, :l.n], wi) and np.array_equal(dist[k, :l.n], wd), k
+        assert (idx[k, l.n:] == -1).all() and (dist[k, l.n:] == 100).all() and (wi >= 0).sum() > l.n // 2
     ctx.free_frames(ids)
 
 
