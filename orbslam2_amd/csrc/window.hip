@@ -311,14 +311,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             const bool hop = have_nxt && hi <= 7 && hi - lo <= 1;
             const uint16_t *nx = l_nxt + (hop ? hi : 0);
             while (more) {
-                if (j >= e) {                                  // next column: one contiguous run of records
-                    if (++ix > x1) more = false;
-                    else {
-                        j = l_cell[ix * ORBM_GRID_ROWS + y0];
-                        e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
-                        if (hop) j = nx[j * 8];
-                    }
-                } else {
+                if (j < e) {
                     const uint32_t jcur = j;
                     const float4 rc = l_rec[j];
                     j = hop ? (uint32_t)nx[(j + 1) * 8] : j + 1;
@@ -330,6 +323,14 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                         if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = (uint16_t)jcur;
                         else if (ncand < cap) row_hi[(ncand - WIN_CACHE) * 64] = w;
                         ncand++;
+                    }
+                }
+                if (j >= e) {                                  // run finished (or empty): the next column, in the same iteration
+                    if (++ix > x1) more = false;
+                    else {
+                        j = l_cell[ix * ORBM_GRID_ROWS + y0];
+                        e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
+                        if (hop) j = nx[j * 8];
                     }
                 }
                 // keeps this ONE loop: without a convergent operation here the compiler splits it into nested

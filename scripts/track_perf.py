@@ -9,6 +9,8 @@ from orbslam2_amd import synth
 from orbslam2_amd.matcher import Context
 from oracle import oracle_ffi as orc
 ctx = Context(0)
+from orbslam2_amd import _lib
+_lib.load().orbm__window_variant(int(os.environ.get('ORBM_WIN_VARIANT', '0')))
 for mode, dth, th, nq in ((0, 100, 7.0, 1500), (0, 100, 15.0, 1500), (1, 100, 7.0, 1500), (2, 50, 10.0, 1500)):
     f, q = synth.window_instance(700 + mode, mode, n=2000, n_queries=nq, th=th, stereo=(mode == 0))
     fid = ctx.upload_frames([f]); qid = ctx.upload_win_queries([q])
