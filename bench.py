@@ -106,6 +106,34 @@ def cpu_baseline(kfs, seconds=12.0):
                       f"as ORBmatcher.cc:2184-2200), {cores} threads x {seconds * 0.75:.0f} s; single thread {n1} pairs"}
 
 
+def popcount_form(ctx, torch, dev, ids):
+    """The same workload through the vector-ALU xor + popcount kernel (ORBMATCH_BF2NN_KERNEL=valu; identical matches): the form
+    BASELINE's north star describes, priced against the integer-popcount roofline."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    fa, fb = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
+    tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
+    m = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
+    ms = []
+    try:
+        L.orbm__bf2nn_variant(11)
+        for rep in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ctx.bf2nn_dev(PAIRS_PER_STEP, tfa.data_ptr(), tfb.data_ptr(), RATIO, TH, N_FEAT, m.data_ptr(), None, None, c.data_ptr())
+            e1.record(); torch.cuda.synchronize()
+            if rep:
+                ms.append(e0.elapsed_time(e1))
+    finally:
+        L.orbm__bf2nn_variant(0)
+    kms = float(np.mean(ms))
+    tcmps = PAIRS_PER_STEP * float(N_FEAT) * N_FEAT / (kms * 1e-3) / 1e12
+    return {"bound": "valu-int-popcount", "kernel": "bf2nn_kernel<2,4,0>", "kernel_ms": round(kms, 4), "achieved": round(tcmps, 4),
+            "peak": round(PEAK_TCMPS, 4), "unit": "T Hamming cmps/s", "frac": round(tcmps / PEAK_TCMPS, 4),
+            "pairs_per_s": round(PAIRS_PER_STEP / (kms * 1e-3), 1),
+            "note": "peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cycles + 8 bcnt x 4 cycles) per comparison"}
+
+
 def secondary(ctx, torch, dev, kfs, ids):
     """Short measurements of the other kernels (parity-tested configs 3/4), reported in `extra`."""
     from orbslam2_amd import synth
@@ -121,16 +149,15 @@ def secondary(ctx, torch, dev, kfs, ids):
         ctx.search_bow_dev(1, 8192, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
         e1.record(); torch.cuda.synchronize()
     out["search_bow_kfkf_pairs_per_s"] = round(8192 / (e0.elapsed_time(e1) * 1e-3), 1)
-    # config 2 again with the other forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount on the
-    # vector ALU (ORBMATCH_BF2NN_KERNEL=valu; the form the reference's arithmetic maps to directly), the same with early
+    # config 2 again with two more forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount with early
     # abandon (ORBMATCH_BF2NN_EARLY_ABANDON=1: the last 64 bits of a comparison are skipped when the first 192 already
-    # reach the tracking bound, so not every distance is evaluated in full), and the int8 MFMA form
+    # reach the tracking bound, so not every distance is evaluated in full) and the int8 MFMA form
     from orbslam2_amd import _lib
     L = _lib.load()
     fa2, fb2 = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
     tfa2 = torch.tensor(fa2, device=dev); tfb2 = torch.tensor(fb2, device=dev)
     m2 = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
-    for variant, name in ((11, "valu_popcount"), (8, "valu_early_abandon"), (9, "mfma_int8")):
+    for variant, name in ((8, "valu_early_abandon"), (9, "mfma_int8")):
         try:
             L.orbm__bf2nn_variant(variant)
             best = 1e30
@@ -144,7 +171,6 @@ def secondary(ctx, torch, dev, kfs, ids):
             L.orbm__bf2nn_variant(0)
         out[f"bf2nn_{name}_pairs_per_s"] = round(PAIRS_PER_STEP / (best * 1e-3), 1)
         out[f"bf2nn_{name}_Gcmps"] = round(PAIRS_PER_STEP * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
-    out["bf2nn_valu_popcount_frac_of_popcount_peak"] = round(out["bf2nn_valu_popcount_Gcmps"] / 1e3 / PEAK_TCMPS, 4)
     # config 4 as stated: ONE frame against 64 candidate keyframes (relocalisation / loop closure), SearchByBoW(KF, F)
     cand = ids[rng.choice(len(ids), 64, replace=False)].astype(np.int32)
     tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(64, ids[0], np.int32), device=dev)
@@ -352,8 +378,15 @@ def main():
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
                          "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
                                  "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz; "
-                                 "the chip holds about 1.5-1.7 GHz in MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back)"},
+                                 "the chip holds about 1.5-2.0 GHz in MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back). "
+                                 "vs_integer_popcount_roofline = achieved cmps/s over the 3.277 T cmps/s that bound the xor + popcount "
+                                 "form of this kernel (roofline_popcount_form: that form, same workload, same run)"},
         }
+        res["roofline"]["vs_integer_popcount_roofline"] = round(achieved_tcmps / PEAK_TCMPS, 3)
+        try:
+            res["roofline_popcount_form"] = popcount_form(ctx, torch, dev, ids)
+        except Exception as e:
+            res["roofline_popcount_form"] = {"error": repr(e)}
         if not args.no_extra:
             try:
                 res["extra"] = secondary(ctx, torch, dev, kfs, ids)
