@@ -131,7 +131,10 @@ def popcount_form(ctx, torch, dev, ids):
     return {"bound": "valu-int-popcount", "kernel": "bf2nn_kernel<2,4,0>", "kernel_ms": round(kms, 4), "achieved": round(tcmps, 4),
             "peak": round(PEAK_TCMPS, 4), "unit": "T Hamming cmps/s", "frac": round(tcmps / PEAK_TCMPS, 4),
             "pairs_per_s": round(PAIRS_PER_STEP / (kms * 1e-3), 1),
-            "note": "peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cycles + 8 bcnt x 4 cycles) per comparison"}
+            "frac_of_survey_peak": round(tcmps / 2.4576, 4),
+            "note": "peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cycles + 8 bcnt x 4 cycles) per comparison (issue rates "
+                    "measured with scripts/ubench_valu*.hip: v_xor is double-rate); SURVEY 8(d) prices all 16 lane-ops at 64 lanes/clk/CU "
+                    "= 2.4576 T cmps/s (frac_of_survey_peak)"}
 
 
 def secondary(ctx, torch, dev, kfs, ids):
