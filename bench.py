@@ -94,6 +94,14 @@ def cpu_baseline(kfs, seconds=12.0):
     t1 = time.perf_counter()
     orc.search_proj_points(f, q, 3.0, 0.8)
     proj_ms = (time.perf_counter() - t1) * 1e3
+    # config 4, SearchByBoW(KF,KF) on one core over a sample of the pair list `extra.search_bow_kfkf_*` runs: time per pair and the
+    # distance evaluations the reference algorithm performs per pair (the oracle's counter)
+    ia, ib = pair_list(np.random.default_rng(3), np.arange(len(kfs)), 8192)
+    bow_cmps = 0
+    t1 = time.perf_counter()
+    for k in range(256):
+        bow_cmps += orc.search_bow(1, kfs[ia[k]], kfs[ib[k]], 0.75, True)[2]
+    bow_pair_ms = (time.perf_counter() - t1) * 1e3 / 256
     # ComputeBoW of one frame on one core (descent of the synthetic k = 10, depth-6 tree; restated DBoW2 transform)
     voc = synth.make_vocabulary_regular()
     t1 = time.perf_counter()
@@ -102,6 +110,7 @@ def cpu_baseline(kfs, seconds=12.0):
     return {"value": round(multi / 1e9, 4), "unit": "G Hamming cmps/s", "cores": cores, "kind": "port",
             "single_thread_value": round(single / 1e9, 4), "single_thread_hw_popcnt_value": round(single_popcnt / 1e9, 4),
             "search_by_projection_single_instance_ms": round(proj_ms, 3), "compute_bow_single_frame_ms": round(bow_ms, 3),
+            "search_bow_kfkf_ms_per_pair": round(bow_pair_ms, 4), "search_bow_kfkf_cmps_per_pair": round(bow_cmps / 256, 1),
             "sample": f"{sum(done)} random keyframe pairs of the bench store ({N_FEAT}x{N_FEAT} brute-force 2-NN, SWAR popcount "
                       f"as ORBmatcher.cc:2184-2200), {cores} threads x {seconds * 0.75:.0f} s; single thread {n1} pairs"}
 
@@ -397,6 +406,9 @@ def main():
                 res["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(kfs)
+            ex, cb = res.get("extra", {}), res["cpu_baseline"]
+            if "search_bow_kfkf_pairs_per_s" in ex:   # BoW-grouped search in the metric's other unit: the reference's evaluations/s
+                ex["search_bow_kfkf_Gcmps"] = round(ex["search_bow_kfkf_pairs_per_s"] * cb["search_bow_kfkf_cmps_per_pair"] / 1e9, 2)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

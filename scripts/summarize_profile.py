@@ -36,6 +36,26 @@ summ = {"tag": tag, "kernel": bf["Name"][:80], "launches_profiled": int(bf["Call
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg_bytes, "sq": sq,
         "valu_insts_per_tile_of_1024_cmps": sq.get("SQ_INSTS_VALU", 0) / (P * N * N / 1024.0) if sq else None,
         "clock_ghz_est": sq.get("GRBM_GUI_ACTIVE", 0) / 8 / float(bf["AverageNs"]) if sq else None}
+# the xor + popcount form of the same search (bench.py `roofline_popcount_form`): vector-ALU utilisation against the
+# integer peak, the evidence BASELINE's north star asks for
+try:
+    VK = "bf2nn_kernel<2, 4, 0>"
+    vsq, _ = counters("sq", VK)
+    for extra_pass in ("sq2",):
+        more, _ = counters(extra_pass, VK); vsq.update(more)
+    vr = [r for r in rows if VK in r["Name"]][0]
+    vns = float(vr["AverageNs"])
+    clk = vsq["GRBM_GUI_ACTIVE"] / 8 / vns                       # GHz
+    simd_cycles = clk * vns * 1024                                # SIMD-cycles the launch offered
+    summ["popcount_form"] = {
+        "kernel": vr["Name"][:60], "avg_kernel_ns": vns, "achieved_Tcmps": P * N * N / vns / 1e3,
+        "frac_of_popcount_roofline_3.277T": P * N * N / vns / 1e3 / 3.2768, "clock_ghz_est": clk,
+        "valu_insts_per_wave_cmp": vsq["SQ_INSTS_VALU"] / (P * N * N / 64.0),
+        "valu_busy_frac": vsq["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles if "SQ_ACTIVE_INST_VALU" in vsq else None,
+        "lanes_active_frac": vsq["SQ_THREAD_CYCLES_VALU"] / (vsq["SQ_ACTIVE_INST_VALU"] * 4 * 64) if "SQ_THREAD_CYCLES_VALU" in vsq else None,
+        "sq": vsq}
+except Exception as e:
+    summ["popcount_form_error"] = repr(e)
 # secondary kernels (bench.py `extra`): windowed SearchByProjection (256 x 50k queries, then one instance alone; two
 # kernels per call: collect_kernel + window_kernel) and SearchByBoW (8192 pairs)
 try:
