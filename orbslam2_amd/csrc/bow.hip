@@ -447,6 +447,15 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                     best = min(best, key);
                 }
             };
+            // the first scan keeps the four smallest keys in order: when claims made meanwhile take candidates away, the
+            // best two of what is left are the first two unclaimed of the four (anything outside the four is larger)
+            auto update4 = [&](uint32_t d, uint32_t t, uint32_t &k0, uint32_t &k1, uint32_t &k2, uint32_t &k3) {
+                uint32_t x = (d << 16) | t, lo;
+                lo = min(k0, x); x = max(k0, x); k0 = lo;
+                lo = min(k1, x); x = max(k1, x); k1 = lo;
+                lo = min(k2, x); x = max(k2, x); k2 = lo;
+                k3 = min(k3, x);
+            };
             // rescan of one lane (rare): candidates claimed meanwhile are left out
             auto scan = [&](bool skip_claimed, uint32_t &best, uint32_t &second) {
                 best = INITKEY; second = INITKEY;
@@ -460,14 +469,17 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
             };
             // ---- scan: every lane against its own node's candidates, claims ignored.  The loads run ahead of the
             // arithmetic: index two candidates ahead, descriptor and flags one ahead (lanes of a node read the same rows).
-            uint32_t best = INITKEY, second = INITKEY;
+            uint32_t best = INITKEY, second = INITKEY, third = INITKEY, fourth = INITKEY;
+            auto note = [&](uint32_t d, uint32_t t) {
+                if (MODE == 2) update(d, t, best, second); else update4(d, t, best, second, third, fourth);
+            };
             if (staged) {
                 const int tmax = wave_max(qvalid ? (int)mNB : 0);
                 for (int t = 0; t < tmax; t++) {
                     if (qvalid && (uint32_t)t < mNB) {
                         int idxB; uint32_t cd[8], fl, d = 0;
                         staged_candidate((uint32_t)t, idxB, cd, fl);
-                        if (evaluate(idxB, cd, fl, false, d)) update(d, (uint32_t)t, best, second);
+                        if (evaluate(idxB, cd, fl, false, d)) note(d, (uint32_t)t);
                     }
                 }
             } else {
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                     idx_nxt = on ? (int)B.fv_idx[mOffB + min((uint32_t)t + 2u, last)] : 0;
                     if (on && (uint32_t)t < mNB) {
                         uint32_t d = 0;
-                        if (evaluate(idxB, cd, fl, false, d)) update(d, (uint32_t)t, best, second);
+                        if (evaluate(idxB, cd, fl, false, d)) note(d, (uint32_t)t);
                     }
                 }
             }
@@ -528,7 +540,20 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                         stale = (claimed[ib2 >> 5] >> (ib2 & 31)) & 1u;
                     }
                     if (stale) {
-                        scan(true, best, second);
+                        const uint32_t kk[4] = {best, second, third, fourth};
+                        uint32_t left[2] = {INITKEY, INITKEY};
+                        int nleft = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            bool gone = false;
+                            if (kk[i] != INITKEY) {                       // INITKEY: the node has no further candidate
+                                const int ib = candidate_index(kk[i] & 0xFFFFu);
+                                gone = (claimed[ib >> 5] >> (ib & 31)) & 1u;
+                            }
+                            if (!gone && nleft < 2) { if (nleft == 0) left[0] = kk[i]; else left[1] = kk[i]; nleft++; }
+                        }
+                        if (nleft == 2) { best = left[0]; second = left[1]; }
+                        else scan(true, best, second);                    // three of the four claimed: look again (rare)
                         if (best != INITKEY) ib1 = candidate_index(best & 0xFFFFu);
                     }
                     const int bd = (int)(best >> 16), sd = (int)(second >> 16);
