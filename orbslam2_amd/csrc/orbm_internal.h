@@ -200,24 +200,24 @@ __device__ __forceinline__ int rot_bin(float a1, float a2) {
 
 // ComputeThreeMaxima, ORBmatcher.cc:2135-2178 (single lane)
 __device__ __forceinline__ void three_maxima(const int *sizes, int &ind1, int &ind2, int &ind3) {
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
+    // (size << 8 | 255 - bin) keys: a larger size ranks first, the lower bin index among equal sizes (strict '>' in a
+    // scan by ascending bin); sizes of 0 never rank (the reference starts from max = 0 with strict '>')
+    uint32_t k1 = 0, k2 = 0, k3 = 0;
+#pragma unroll 1
     for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
         const int s = sizes[i];
-        if (s > max1) {
-            max3 = max2; max2 = max1; max1 = s;
-            ind3 = ind2; ind2 = ind1; ind1 = i;
-        } else if (s > max2) {
-            max3 = max2; max2 = s;
-            ind3 = ind2; ind2 = i;
-        } else if (s > max3) {
-            max3 = s; ind3 = i;
-        }
+        uint32_t x = s > 0 ? ((uint32_t)s << 8) | (uint32_t)(255 - i) : 0u, hi;
+        hi = max(k1, x); x = min(k1, x); k1 = hi;
+        hi = max(k2, x); x = min(k2, x); k2 = hi;
+        k3 = max(k3, x);
     }
+    const int max1 = (int)(k1 >> 8), max2 = (int)(k2 >> 8), max3 = (int)(k3 >> 8);
+    int a1 = k1 ? 255 - (int)(k1 & 255u) : -1, a2 = k2 ? 255 - (int)(k2 & 255u) : -1, a3 = k3 ? 255 - (int)(k3 & 255u) : -1;
     if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
-        ind2 = -1; ind3 = -1;
+        a2 = -1; a3 = -1;
     } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
-        ind3 = -1;
+        a3 = -1;
     }
+    ind1 = a1; ind2 = a2; ind3 = a3;
 }
 #endif

@@ -523,13 +523,15 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 }
                 if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                    // :608
                 if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                       // this query may still claim k
-                if (dist < bestDist) {
-                    bestDist2 = bestDist; bestDist = dist;
-                    bestLevel2 = bestLevel; bestLevel = oct;
-                    bestIdx2 = bestIdx; bestIdx = k;
-                } else if (dist < bestDist2) {
-                    bestLevel2 = oct; bestDist2 = dist; bestIdx2 = k;
-                }
+                // strict '<' on the best, else strict '<' on the second (:124-137 etc.), as selects: with branches the
+                // compiler keeps the two indices in a scratch-memory array and stores through a computed offset
+                const bool b1 = dist < bestDist, b2 = !b1 && dist < bestDist2;
+                bestDist2 = b1 ? bestDist : (b2 ? dist : bestDist2);
+                bestLevel2 = b1 ? bestLevel : (b2 ? oct : bestLevel2);
+                bestIdx2 = b1 ? bestIdx : (b2 ? k : bestIdx2);
+                bestDist = b1 ? dist : bestDist;
+                bestLevel = b1 ? oct : bestLevel;
+                bestIdx = b1 ? k : bestIdx;
             };
             // ---- evaluate ---------------------------------------------------------------------------
             if (unresolved) {
