@@ -20,9 +20,9 @@ constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
 constexpr int BOWQ_STAGE = 128;   // candidate rows a wave keeps in LDS for one group of queries
 
-__device__ __forceinline__ void load_row(const uint32_t *desc, int idx, uint32_t (&r)[8]) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)idx;
-    const uint4 lo = p[0], hi = p[1];
+__device__ __forceinline__ void load_row(gptr<const uint32_t> desc, int idx, uint32_t (&r)[8]) {
+    const gptr<const v4u> p = (gptr<const v4u>)desc + 2 * (size_t)idx;
+    const v4u lo = p[0], hi = p[1];
     r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
 }
 
@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ int find_node(const uint32_t *nodes, int n, uint32_t key) {
+__device__ __forceinline__ int find_node(gptr<const uint32_t> nodes, int n, uint32_t key) {
     int lo = 0, hi = n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
     const int p = SPLIT ? (int)blockIdx.x / splits : (int)xcd_remap(blockIdx.x, gridDim.x);
     const int part = SPLIT ? (int)blockIdx.x - p * splits : 0;
     const int nparts = SPLIT ? splits : 1;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
     if (tid == 0) nmatches = 0;
     __syncthreads();
 
-    const float *angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
+    const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float ex = 0.f, ey = 0.f;
     if (MODE == 2) {
@@ -291,8 +290,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     const int p = SPLIT ? (int)blockIdx.x / splits : (int)xcd_remap(blockIdx.x, gridDim.x);
     const int part = SPLIT ? (int)blockIdx.x - p * splits : 0;
     const int nparts = SPLIT ? splits : 1;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
@@ -306,7 +304,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     uint32_t *w_meta = s_meta[wave];
     uint32_t *w_pos = s_pos[wave];
 
-    const float *angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
+    const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float ex = 0.f, ey = 0.f;
     if (MODE == 2) {
@@ -401,9 +399,10 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                 if (my_node >= 0)
                     for (uint32_t t = (uint32_t)my_s; t < mNB; t += my_take) {
                         const int idxB = (int)B.fv_idx[mOffB + t];
-                        const uint4 *g = reinterpret_cast<const uint4 *>(B.desc) + 2 * (size_t)idxB;
-                        w_rows[2 * (my_cbase + t)] = g[0];
-                        w_rows[2 * (my_cbase + t) + 1] = g[1];
+                        const gptr<const v4u> g = (gptr<const v4u>)B.desc + 2 * (size_t)idxB;
+                        const v4u g0 = g[0], g1 = g[1];
+                        w_rows[2 * (my_cbase + t)] = make_uint4(g0.x, g0.y, g0.z, g0.w);
+                        w_rows[2 * (my_cbase + t) + 1] = make_uint4(g1.x, g1.y, g1.z, g1.w);
                         w_meta[my_cbase + t] = (uint32_t)idxB | ((uint32_t)B.mp_flags[idxB] << 16);
                     }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -610,10 +609,9 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
     __shared__ int keep[3];
     __shared__ int removed_all;
     const int p = blockIdx.x, tid = threadIdx.x;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nOut = MODE == 0 ? B.n : A.n;
-    const float *angB = MODE == 0 ? B.angle_raw : B.angle;
+    const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;
     int32_t *match = match_all + (size_t)p * stride;
     if (tid < ORBM_HISTO_LENGTH) hist[tid] = pair_acc[p * 32 + tid];
     if (tid == 0) removed_all = 0;

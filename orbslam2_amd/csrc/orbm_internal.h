@@ -161,6 +161,51 @@ struct IoStage {
 
 // ---- device helpers (gfx950) -------------------------------------------------------------------
 #ifdef __HIPCC__
+// A pointer that device code reads from a table in memory is a "flat" pointer to the compiler: every access through it is
+// a flat_load (counts on both wait counters, so it also holds up LDS reads, and takes no scalar base).  Typed as a
+// pointer into the global address space the accesses become global_loads.  FrameG / QSetG are FrameDev / QSetDev with
+// such pointers: same member names, built once at the top of a kernel (members a kernel does not use cost nothing).
+#define ORBM_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));   // 16-byte loads through such pointers (HIP's uint4 / float4 are
+typedef float v4f __attribute__((ext_vector_type(4)));      // classes whose copy constructors take flat references)
+template <class T>
+using gptr = ORBM_GLOBAL T *;
+template <class T>
+__device__ __forceinline__ gptr<T> in_global(T *p) {
+    return (gptr<T>)p;
+}
+struct FrameG {
+    int32_t n, n_nodes, n_levels;
+    gptr<const uint32_t> desc;
+    gptr<const float> x, y, angle, angle_raw, uright;
+    gptr<const uint8_t> octave;
+    gptr<uint8_t> mp_flags;
+    gptr<uint32_t> cell_off, cell_idx;
+    gptr<const v4f> cell_rec;
+    gptr<uint16_t> cell_nxt;
+    gptr<const uint32_t> fv_node, fv_off, fv_idx, desc8, desc4;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+    gptr<const float> sf, sigma2;
+    __device__ __forceinline__ explicit FrameG(const FrameDev &f)
+        : n(f.n), n_nodes(f.n_nodes), n_levels(f.n_levels), desc(in_global(f.desc)), x(in_global(f.x)), y(in_global(f.y)),
+          angle(in_global(f.angle)), angle_raw(in_global(f.angle_raw)), uright(in_global(f.uright)), octave(in_global(f.octave)),
+          mp_flags(in_global(f.mp_flags)), cell_off(in_global(f.cell_off)), cell_idx(in_global(f.cell_idx)),
+          cell_rec((gptr<const v4f>)f.cell_rec), cell_nxt(in_global(f.cell_nxt)), fv_node(in_global(f.fv_node)),
+          fv_off(in_global(f.fv_off)), fv_idx(in_global(f.fv_idx)), desc8(in_global(f.desc8)), desc4(in_global(f.desc4)),
+          min_x(f.min_x), min_y(f.min_y), max_x(f.max_x), max_y(f.max_y), inv_w(f.inv_w), inv_h(f.inv_h),
+          sf(in_global(&f.sf[0])), sigma2(in_global(&f.sigma2[0])) {}
+};
+struct QSetG {
+    int32_t n, kind;
+    gptr<const uint32_t> desc;
+    gptr<const float> f0, f1, f2, f3, angle;
+    gptr<const int32_t> l0, l1;
+    gptr<const uint8_t> flags;
+    __device__ __forceinline__ explicit QSetG(const QSetDev &q)
+        : n(q.n), kind(q.kind), desc(in_global(q.desc)), f0(in_global(q.f0)), f1(in_global(q.f1)), f2(in_global(q.f2)),
+          f3(in_global(q.f3)), angle(in_global(q.angle)), l0(in_global(q.l0)), l1(in_global(q.l1)), flags(in_global(q.flags)) {}
+};
+
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
