@@ -82,8 +82,7 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int p = bid / blocks_per_pair;
     const int qb = bid - p * blocks_per_pair;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nA = A.n, nB = B.n;
     const int tid = threadIdx.x;
     const int q0 = qb * (256 * R) + tid;
@@ -91,11 +90,11 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
 
     uint32_t q[R][8];
     uint32_t best[R], second[R], bias[R];
-    const uint4 *Ad = reinterpret_cast<const uint4 *>(A.desc);
+    const gptr<const v4u> Ad = (gptr<const v4u>)A.desc;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = q0 + r * 256;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        v4u lo = {0, 0, 0, 0}, hi = lo;
         if (qi < nA) { lo = Ad[2 * qi]; hi = Ad[2 * qi + 1]; }
         q[r][0] = lo.x; q[r][1] = lo.y; q[r][2] = lo.z; q[r][3] = lo.w;
         q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
@@ -104,11 +103,14 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
         bias[r] = 0x80000000u - (uint32_t)min(256, track_below);
     }
 
-    const uint4 *Bd = reinterpret_cast<const uint4 *>(B.desc);
+    const gptr<const v4u> Bd = (gptr<const v4u>)B.desc;
     for (int t0 = 0; t0 < nB; t0 += BF_TILE) {
         const int rows = min(BF_TILE, nB - t0);
         __syncthreads();
-        for (int i = tid; i < rows * 2; i += 256) tile[i] = Bd[t0 * 2 + i];
+        for (int i = tid; i < rows * 2; i += 256) {
+            const v4u row = Bd[t0 * 2 + i];
+            tile[i] = make_uint4(row.x, row.y, row.z, row.w);
+        }
         __syncthreads();
         int j = 0;
         for (; j + U <= rows; j += U) {
@@ -225,8 +227,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int p = bid / blocks_per_pair;
     const int qb = bid - p * blocks_per_pair;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nA = A.n, nB = B.n;
     if (qb * 256 >= nA) return;        // whole block idle (uniform)
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int row = min(qbase + t * 32 + col, nA8 - 1);
-        const v4i *src = reinterpret_cast<const v4i *>(A.desc8) + (size_t)row * 16;
+        const gptr<const v4i> src = (gptr<const v4i>)A.desc8 + (size_t)row * 16;
 #pragma unroll
         for (int s = 0; s < 8; s++) bq[t][s] = src[2 * s + h];
     }
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
         T[t] = 256 - 2 * min(256, track_below);
     }
 
-    const v4i *Bd8 = reinterpret_cast<const v4i *>(B.desc8);
+    const gptr<const v4i> Bd8 = (gptr<const v4i>)B.desc8;
     for (int c0 = 0; c0 < nB8; c0 += MF_ROWS) {
         const int rows = min(MF_ROWS, nB8 - c0);            // a multiple of 32
         if (DIAG != 2 || c0 == 0) {
@@ -351,8 +352,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int p = bid / blocks_per_pair;
     const int qb = bid - p * blocks_per_pair;
-    const FrameDev &A = table[fa[p]];
-    const FrameDev &B = table[fb[p]];
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nA = A.n, nB = B.n;
     constexpr int QW = 32 * NT;        // queries per wave: NT tiles of 32
     if (qb * (4 * QW) >= nA) return;   // whole block idle (uniform)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int row = min(qbase + t * 32 + col, nA8 - 1);
-        const v4i *src = reinterpret_cast<const v4i *>(A.desc4) + (size_t)row * 8;
+        const gptr<const v4i> src = (gptr<const v4i>)A.desc4 + (size_t)row * 8;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const v4i x = src[2 * s + h];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     }
     const int one = 0x7F7F7F7F;        // E8M0 block scale 2^0 in every byte
 
-    const v4i *Bd4 = reinterpret_cast<const v4i *>(B.desc4);
+    const gptr<const v4i> Bd4 = (gptr<const v4i>)B.desc4;
     // Two LDS buffers of MF4_ROWS / 2 rows; the next stage travels global -> LDS directly (global_load_lds, no registers)
     // while the current one is multiplied; one barrier per stage.  A wave instruction fills 1 KB = 8 rows of LDS in lane
     // order, so the swizzle is applied to the global address each lane reads: LDS chunk position (r, cpos) holds chunk
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
             const int g0 = __builtin_amdgcn_readfirstlane((wave * INSTR_PER_WAVE + j) * 64);
             const int g = g0 + l, r = g >> 3, cpos = g & 7;
             const int row = min(c0 + r, nB8 - 1);
-            const v4i *src = Bd4 + (size_t)row * 8 + (cpos ^ ((r >> 1) & 7));
+            const gptr<const v4i> src = Bd4 + (size_t)row * 8 + (cpos ^ ((r >> 1) & 7));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(tile + buf * (HALF * 8) + g0), 16, 0, 0);
         }

@@ -20,7 +20,9 @@ __global__ __launch_bounds__(64) void bow_score_kernel(const BowVecDev *__restri
                                                        int32_t *__restrict__ common) {
     extern __shared__ uint32_t qw[];
     const int p = blockIdx.x, lane = threadIdx.x;
-    const BowVecDev A = table[va[p]], B = table[vb[p]];
+    struct { int32_t n; gptr<const uint32_t> word; gptr<const double> value; } A, B;    // pointers from a table: typed global
+    A.n = table[va[p]].n; A.word = in_global(table[va[p]].word); A.value = in_global(table[va[p]].value);
+    B.n = table[vb[p]].n; B.word = in_global(table[vb[p]].word); B.value = in_global(table[vb[p]].value);
     for (int i = lane; i < A.n; i += 64) qw[i] = A.word[i];
     __syncthreads();
     double acc = 0.0;

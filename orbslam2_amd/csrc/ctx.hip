@@ -169,7 +169,7 @@ int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const c
 // One workgroup per frame: LDS histogram over the 3072 cells, block scan, scatter, then every cell's
 // short list is put in ascending keypoint order (the reference appends in index order).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pos_in_grid(const FrameDev &f, int i) {
+__device__ __forceinline__ int pos_in_grid(const FrameG &f, int i) {
     const int posX = (int)roundf(__fmul_rn(__fsub_rn(f.x[i], f.min_x), f.inv_w));
     const int posY = (int)roundf(__fmul_rn(__fsub_rn(f.y[i], f.min_y), f.inv_h));
     if (posX < 0 || posX >= ORBM_GRID_COLS || posY < 0 || posY >= ORBM_GRID_ROWS) return -1;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     __shared__ uint32_t off[ORBM_GRID_CELLS + 1];
     __shared__ uint32_t part[256];
     __shared__ uint16_t lidx[GRID_LDS_MAX_N];
-    const FrameDev &f = table[ids[blockIdx.x]];
+    const FrameG f(table[ids[blockIdx.x]]);
     const int tid = threadIdx.x;
     const int n = f.n;
     const bool in_lds = n <= GRID_LDS_MAX_N;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     for (uint32_t i = tid; i < total; i += 256) {
         const uint32_t k = in_lds ? (uint32_t)lidx[i] : f.cell_idx[i];
         if (in_lds) f.cell_idx[i] = k;
-        f.cell_rec[i] = make_float4(f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16)));
+        ((gptr<v4f>)f.cell_rec)[i] = v4f{f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16))};
     }
     // skip lists over the cell-ordered stream, one per octave pair {p-1, p}: suffix "first match at or after j".
     // Each thread owns a run of consecutive positions; the carry from the runs to its right is a suffix-min.
@@ -295,19 +295,19 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
             for (int w = wv + 1; w < 4; w++) carry[p2] = min(carry[p2], (uint32_t)firstm[w * 8 + p2]);
             if (carry[p2] == 0xFFFFu) carry[p2] = total;
         }
-        uint4 *nxt4 = reinterpret_cast<uint4 *>(f.cell_nxt);
+        const gptr<v4u> nxt4 = (gptr<v4u>)f.cell_nxt;
         if (j1 == (int)total) {
             // whoever owns the end of the stream also writes the sentinel row (several threads may: same values)
             const uint32_t tt = total | (total << 16);
-            nxt4[total] = make_uint4(tt, tt, tt, tt);
+            nxt4[total] = v4u{tt, tt, tt, tt};
         }
         for (int j = j1 - 1; j >= j0; j--) {
             const int o = loct[j];
 #pragma unroll
             for (int p2 = 0; p2 < 8; p2++)
                 if (o == p2 || o == p2 - 1) carry[p2] = (uint32_t)j;
-            nxt4[j] = make_uint4(carry[0] | (carry[1] << 16), carry[2] | (carry[3] << 16), carry[4] | (carry[5] << 16),
-                                 carry[6] | (carry[7] << 16));
+            nxt4[j] = v4u{carry[0] | (carry[1] << 16), carry[2] | (carry[3] << 16), carry[4] | (carry[5] << 16),
+                          carry[6] | (carry[7] << 16)};
         }
     }
 }
@@ -759,11 +759,11 @@ template <int BITS>
 __global__ __launch_bounds__(256) void expand_image_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int blocks_per_frame) {
     constexpr int CHUNKS = BITS == 8 ? 16 : 8;          // 16-byte chunks per output row
     const int f = blockIdx.x / blocks_per_frame;
-    const FrameDev &F = table[ids[f]];
+    const FrameG F(table[ids[f]]);
     const int row = (blockIdx.x - f * blocks_per_frame) * (256 / CHUNKS) + (int)(threadIdx.x / CHUNKS), chunk = threadIdx.x % CHUNKS;
     const int n8 = max(32, (F.n + 31) & ~31);
     if (row >= n8) return;
-    uint4 out = make_uint4(0, 0, 0, 0);
+    v4u out = {0, 0, 0, 0};
     if (row < F.n) {
         uint32_t o[4];
         if (BITS == 8) {
@@ -786,10 +786,9 @@ __global__ __launch_bounds__(256) void expand_image_kernel(FrameDev *__restrict_
                 o[q] = v;
             }
         }
-        out = make_uint4(o[0], o[1], o[2], o[3]);
+        out = v4u{o[0], o[1], o[2], o[3]};
     }
-    uint32_t *base = const_cast<uint32_t *>(BITS == 8 ? F.desc8 : F.desc4);
-    reinterpret_cast<uint4 *>(base)[(size_t)row * CHUNKS + chunk] = out;
+    ((gptr<v4u>)(BITS == 8 ? F.desc8 : F.desc4))[(size_t)row * CHUNKS + chunk] = out;
 }
 
 int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {

@@ -186,6 +186,7 @@ struct FrameG {
     gptr<const uint32_t> fv_node, fv_off, fv_idx, desc8, desc4;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     gptr<const float> sf, sigma2;
+    FrameG() = default;
     __device__ __forceinline__ explicit FrameG(const FrameDev &f)
         : n(f.n), n_nodes(f.n_nodes), n_levels(f.n_levels), desc(in_global(f.desc)), x(in_global(f.x)), y(in_global(f.y)),
           angle(in_global(f.angle)), angle_raw(in_global(f.angle_raw)), uright(in_global(f.uright)), octave(in_global(f.octave)),
@@ -201,6 +202,7 @@ struct QSetG {
     gptr<const float> f0, f1, f2, f3, angle;
     gptr<const int32_t> l0, l1;
     gptr<const uint8_t> flags;
+    QSetG() = default;
     __device__ __forceinline__ explicit QSetG(const QSetDev &q)
         : n(q.n), kind(q.kind), desc(in_global(q.desc)), f0(in_global(q.f0)), f1(in_global(q.f1)), f2(in_global(q.f2)),
           f3(in_global(q.f3)), angle(in_global(q.angle)), l0(in_global(q.l0)), l1(in_global(q.l1)), flags(in_global(q.flags)) {}

@@ -22,13 +22,12 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_kernel(const FrameDev *__re
                                                      const int32_t *__restrict__ fr, const float *__restrict__ max_d,
                                                      int blocks_per_pair, int stride, int32_t *__restrict__ best_idx,
                                                      int32_t *__restrict__ best_dist) {
-    __shared__ uint4 s_desc[2 * ST_TILE];
+    __shared__ v4u s_desc[2 * ST_TILE];
     __shared__ float s_x[ST_TILE];
     __shared__ int s_minr[ST_TILE], s_maxr[ST_TILE], s_oct[ST_TILE];
     const int p = blockIdx.x / blocks_per_pair;
     const int iL = (blockIdx.x - p * blocks_per_pair) * ST_THREADS + (int)threadIdx.x;
-    const FrameDev &L = table[fl[p]];
-    const FrameDev &R = table[fr[p]];
+    const FrameG L(table[fl[p]]), R(table[fr[p]]);
     const int tid = threadIdx.x;
     const bool have = iL < L.n;
     uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -36,8 +35,8 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_kernel(const FrameDev *__re
     int row = 0, levelL = 0;
     bool live = false;
     if (have) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(L.desc) + 2 * (size_t)iL;
-        const uint4 lo = g[0], hi = g[1];
+        const gptr<const v4u> g = (gptr<const v4u>)L.desc + 2 * (size_t)iL;
+        const v4u lo = g[0], hi = g[1];
         q[0] = lo.x; q[1] = lo.y; q[2] = lo.z; q[3] = lo.w; q[4] = hi.x; q[5] = hi.y; q[6] = hi.z; q[7] = hi.w;
         uL = L.x[iL];
         row = (int)L.y[iL];                                   // vRowIndices[vL]: float -> index truncation (:684)
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_kernel(const FrameDev *__re
         for (int t = tid; t < ST_TILE; t += ST_THREADS) {
             const int j = base + t;
             if (j < R.n) {
-                const uint4 *g = reinterpret_cast<const uint4 *>(R.desc) + 2 * (size_t)j;
+                const gptr<const v4u> g = (gptr<const v4u>)R.desc + 2 * (size_t)j;
                 s_desc[2 * t] = g[0]; s_desc[2 * t + 1] = g[1];
                 const float kpY = R.y[j];
                 const int o = R.octave[j];
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_kernel(const FrameDev *__re
                             !(o < levelL - 1 || o > levelL + 1) &&                     // :712
                             uR >= minU && uR <= uL;                                    // :717
             if (!__any(ok)) continue;                                                  // wave-uniform
-            const uint4 lo = s_desc[2 * c], hi = s_desc[2 * c + 1];
+            const v4u lo = s_desc[2 * c], hi = s_desc[2 * c + 1];
             const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const int dist = (int)hamming256(q, cd);
             if (ok && dist < bestDist) { bestDist = dist; bestIdxR = base + c; }      // :722-726
@@ -103,8 +102,7 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_sorted_kernel(const FrameDe
     __shared__ uint32_t s_cursor[ST_BINS];
     const int p = blockIdx.x / blocks_per_pair;
     const int iL = (blockIdx.x - p * blocks_per_pair) * ST_THREADS + (int)threadIdx.x;
-    const FrameDev &L = table[fl[p]];
-    const FrameDev &R = table[fr[p]];
+    const FrameG L(table[fl[p]]), R(table[fr[p]]);
     const int tid = threadIdx.x, nR = R.n;
     uint32_t *s_start = reinterpret_cast<uint32_t *>(s_entry + nR);
     auto band = [&](int j, int &minr, int &maxr, int &o) {
@@ -153,8 +151,8 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_sorted_kernel(const FrameDe
         if (iL < stride) { best_idx[(size_t)p * stride + iL] = -1; best_dist[(size_t)p * stride + iL] = ORBM_TH_HIGH; }
         return;
     }
-    const uint4 *g = reinterpret_cast<const uint4 *>(L.desc) + 2 * (size_t)iL;
-    const uint4 qlo = g[0], qhi = g[1];
+    const gptr<const v4u> g = (gptr<const v4u>)L.desc + 2 * (size_t)iL;
+    const v4u qlo = g[0], qhi = g[1];
     const uint32_t q[8] = {qlo.x, qlo.y, qlo.z, qlo.w, qhi.x, qhi.y, qhi.z, qhi.w};
     const float uL = L.x[iL];
     const int row = (int)L.y[iL];                                       // vRowIndices[vL]: float -> index truncation (:684)
@@ -175,8 +173,8 @@ __global__ __launch_bounds__(ST_THREADS) void stereo_sorted_kernel(const FrameDe
             if (row < (int)en.y || row > (int)en.z) continue;           // row band (:658-659)
             if (o < levelL - 1 || o > levelL + 1) continue;             // :712
             if (!(uR >= minU && uR <= uL)) continue;                    // :717
-            const uint4 *c = reinterpret_cast<const uint4 *>(R.desc) + 2 * (size_t)j;
-            const uint4 lo4 = c[0], hi4 = c[1];
+            const gptr<const v4u> c = (gptr<const v4u>)R.desc + 2 * (size_t)j;
+            const v4u lo4 = c[0], hi4 = c[1];
             const uint32_t cd[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
             const uint32_t dist = hamming256(q, cd);
             if (dist < (uint32_t)ORBM_TH_HIGH) best = min(best, (dist << 16) | (uint32_t)j);   // :722-726

@@ -29,12 +29,12 @@ constexpr int VOC_MAX_CHILDREN = 65535;
 // wave-uniform (descents that reached a leaf idle until the whole wave has), loads of lanes without a child go to
 // row 0, so the cross-lane steps never read a lane that sits out.
 template <int NF>
-__device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restrict__ const (&g)[NF], int levelsup, int32_t (&word)[NF], int (&nid)[NF], int (&leaf)[NF]) {
+__device__ __forceinline__ void descend(const VocabDev &V, const gptr<const v4u> (&g)[NF], int levelsup, int32_t (&word)[NF], int (&nid)[NF], int (&leaf)[NF]) {
     const uint32_t sub = threadIdx.x & (VOC_GROUP - 1);
     uint32_t q[NF][8];
 #pragma unroll
     for (int u = 0; u < NF; u++) {
-        const uint4 lo = g[u][0], hi = g[u][1];
+        const v4u lo = g[u][0], hi = g[u][1];
         q[u][0] = lo.x; q[u][1] = lo.y; q[u][2] = lo.z; q[u][3] = lo.w; q[u][4] = hi.x; q[u][5] = hi.y; q[u][6] = hi.z; q[u][7] = hi.w;
     }
     const int nid_level = V.depth - levelsup;
@@ -68,10 +68,10 @@ __device__ __forceinline__ void descend(const VocabDev &V, const uint4 *__restri
                 for (int u = 0; u < NF; u++)
                     if (j < cnt[u] && (rec[u].y >> 31) == 0) id[u] = V.child_idx[id[u]];
             }
-            uint4 clo[NF], chi[NF];
+            v4u clo[NF], chi[NF];
 #pragma unroll
             for (int u = 0; u < NF; u++) {
-                const uint4 *cg = reinterpret_cast<const uint4 *>(V.desc) + 2 * (size_t)id[u];
+                const gptr<const v4u> cg = (gptr<const v4u>)V.desc + 2 * (size_t)id[u];
                 clo[u] = cg[0]; chi[u] = cg[1];
             }
 #pragma unroll
@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256) void transform_kernel(const FrameDev *__restri
                                                         int32_t *__restrict__ leaf_out) {
     const int f = blockIdx.x / blocks_per_frame;
     const int i0 = ((blockIdx.x - f * blocks_per_frame) * (256 / VOC_GROUP) + (int)(threadIdx.x / VOC_GROUP)) * NF;
-    const FrameDev &F = table[ids[f]];
+    const FrameG F(table[ids[f]]);
     const int n = F.n;
     if (n == 0) return;                            // block-uniform
-    const uint4 *g[NF];
+    gptr<const v4u> g[NF];
 #pragma unroll
-    for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(F.desc) + 2 * (size_t)min(i0 + u, n - 1);
+    for (int u = 0; u < NF; u++) g[u] = (gptr<const v4u>)F.desc + 2 * (size_t)min(i0 + u, n - 1);
     int32_t w[NF]; int nid[NF], leaf[NF];
     descend<NF>(V, g, levelsup, w, nid, leaf);
     const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
@@ -128,9 +128,9 @@ template <int NF>
 __global__ __launch_bounds__(256) void transform_flat_kernel(const uint32_t *__restrict__ desc, int n, VocabDev V, int levelsup,
                                                              int32_t *__restrict__ word_out, int32_t *__restrict__ node_out) {
     const int i0 = (blockIdx.x * (256 / VOC_GROUP) + (int)(threadIdx.x / VOC_GROUP)) * NF;
-    const uint4 *g[NF];
+    gptr<const v4u> g[NF];
 #pragma unroll
-    for (int u = 0; u < NF; u++) g[u] = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)min(i0 + u, n - 1);
+    for (int u = 0; u < NF; u++) g[u] = (gptr<const v4u>)desc + 2 * (size_t)min(i0 + u, n - 1);
     int32_t w[NF]; int nid[NF], leaf[NF];
     descend<NF>(V, g, levelsup, w, nid, leaf);
     const int sub = (int)(threadIdx.x & (VOC_GROUP - 1));
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FVB_THREADS) void fv_build_kernel(FrameDev *__restr
             }
             __syncthreads();
         }
-    uint32_t *fv_node = const_cast<uint32_t *>(F.fv_node), *fv_off = const_cast<uint32_t *>(F.fv_off), *fv_idx = const_cast<uint32_t *>(F.fv_idx);
+    const gptr<uint32_t> fv_node = (gptr<uint32_t>)F.fv_node, fv_off = (gptr<uint32_t>)F.fv_off, fv_idx = (gptr<uint32_t>)F.fv_idx;
     // run heads: thread t owns positions [t*per, (t+1)*per); exclusive scan of the head counts over the workgroup
     const int per = (n + FVB_THREADS - 1) / FVB_THREADS;
     const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(FVB_THREADS) void bv_build_kernel(const FrameDev *_
             __syncthreads();
         }
     BowVecDev &out = bv_table[bv_ids[f]];
-    uint32_t *o_word = const_cast<uint32_t *>(out.word);
-    double *o_val = const_cast<double *>(out.value);
+    const gptr<uint32_t> o_word = (gptr<uint32_t>)out.word;
+    const gptr<double> o_val = (gptr<double>)out.value;
     const int per = (n + FVB_THREADS - 1) / FVB_THREADS;
     const int p0 = min(n, tid * per), p1 = min(n, p0 + per);
     uint32_t heads = 0;

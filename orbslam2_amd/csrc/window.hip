@@ -27,6 +27,7 @@
 #include <limits.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include "orbm_internal.h"
 
 namespace {
@@ -49,11 +50,13 @@ struct WinParams {
     int dist_th, check_ori, stride, window;
 };
 
-// Read-only frame data the walk and the distance loop touch, either in global memory or staged in LDS.
-struct FrameAcc {
-    const uint32_t *cell_off;   // 3073
-    const float4 *rec;          // cell-ordered {x, y, uright, idx | oct << 16}
-    const uint4 *desc;          // 2 per keypoint
+// Read-only frame data the walk and the distance loop touch, either in global memory (typed so: global_load) or
+// staged in LDS.
+template <bool LDS>
+struct FrameAccT {
+    std::conditional_t<LDS, const uint32_t *, gptr<const uint32_t>> cell_off;   // 3073
+    std::conditional_t<LDS, const v4f *, gptr<const v4f>> rec;                  // cell-ordered {x, y, uright, idx | oct << 16}
+    std::conditional_t<LDS, const v4u *, gptr<const v4u>> desc;                 // 2 per keypoint
     float min_x, min_y, inv_w, inv_h;
 };
 
@@ -61,8 +64,8 @@ struct FrameAcc {
 // calls body(k, octave, uright) for every keypoint the reference would push, in the reference's order
 // (ix ascending, iy ascending, insertion order).  Cells (ix, minY..maxY) are consecutive in the CSR, so a
 // column of the window is ONE contiguous run of 16-byte records.
-template <bool KF_MODE, typename Body>
-__device__ __forceinline__ void walk_window(const FrameAcc &f, float x, float y, float r, int minLevel, int maxLevel,
+template <bool KF_MODE, typename Acc, typename Body>
+__device__ __forceinline__ void walk_window(const Acc &f, float x, float y, float r, int minLevel, int maxLevel,
                                             Body &&body) {
     const float xr = __fsub_rn(x, f.min_x), yr = __fsub_rn(y, f.min_y);
     const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), f.inv_w)));
@@ -78,7 +81,7 @@ __device__ __forceinline__ void walk_window(const FrameAcc &f, float x, float y,
         const uint32_t b = f.cell_off[ix * ORBM_GRID_ROWS + nMinCellY];
         const uint32_t e = f.cell_off[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
         for (uint32_t j = b; j < e; j++) {
-            const float4 rc = f.rec[j];
+            const v4f rc = f.rec[j];
             const uint32_t w = __float_as_uint(rc.w);
             const int oct = (int)(w >> 16);
             if (bCheckLevels) {
@@ -95,7 +98,7 @@ constexpr int SCAN_U = 8;      // split form: queries scanned for liveness per l
 constexpr int WIN_CACHE = 16;  // candidates remembered per query (registers); wider windows fall back to re-walking
 
 struct Query {
-    uint4 d0, d1;
+    v4u d0, d1;
     float x, y, r, xr, angle;
     int minL, maxL, ql;
     uint32_t flags;
@@ -104,51 +107,50 @@ struct Query {
 
 // where an instance's queries come from: a query set, or (MODE_INIT) the keypoints of frame 1
 struct QSrc {
-    const QSetDev *QS;
-    const FrameDev *F1;
+    QSetG QS;
+    FrameG F1;
     int Q;
 };
 
 template <int MODE>
 __device__ __forceinline__ QSrc query_source(const WinParams &P, int inst) {
     QSrc S;
-    S.QS = nullptr; S.F1 = nullptr;
-    if (MODE == MODE_INIT) { S.F1 = &P.frames[P.qset_ids[inst]]; S.Q = S.F1->n; }
-    else { S.QS = &P.qsets[P.qset_ids[inst]]; S.Q = S.QS->n; }
+    if (MODE == MODE_INIT) { S.F1 = FrameG(P.frames[P.qset_ids[inst]]); S.Q = S.F1.n; }
+    else { S.QS = QSetG(P.qsets[P.qset_ids[inst]]); S.Q = S.QS.n; }
     return S;
 }
 
 // everything of query qi except its descriptor (F = the frame searched)
 template <int MODE>
-__device__ __forceinline__ Query load_params(const WinParams &P, const FrameDev &F, const QSrc &S, int qi) {
+__device__ __forceinline__ Query load_params(const WinParams &P, const FrameG &F, const QSrc &S, int qi) {
     Query q;
-    q.d0 = q.d1 = make_uint4(0, 0, 0, 0);
+    q.d0 = q.d1 = v4u{0, 0, 0, 0};
     q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.ql = 0; q.flags = 0; q.valid = false;
     if (qi >= S.Q) return q;
     if (MODE == MODE_INIT) {
-        if (S.F1->octave[qi] == 0) {                                                  // :582-584
+        if (S.F1.octave[qi] == 0) {                                                  // :582-584
             q.valid = true;
             q.x = P.prev_xy[2 * qi]; q.y = P.prev_xy[2 * qi + 1];
             q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
-            q.angle = S.F1->angle[qi];
+            q.angle = S.F1.angle[qi];
         }
     } else {
-        const QSetDev *QS = S.QS;
-        q.flags = QS->flags[qi];
+        const QSetG &QS = S.QS;
+        q.flags = QS.flags[qi];
         if (q.flags & ORBM_Q_VALID) {
             q.valid = true;
-            q.x = QS->f0[qi]; q.y = QS->f1[qi];
+            q.x = QS.f0[qi]; q.y = QS.f1[qi];
             if (MODE == MODE_PROJ) {
-                const int lvl = QS->l0[qi];
-                float rv = ((double)QS->f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
+                const int lvl = QS.l0[qi];
+                float rv = ((double)QS.f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
                 if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                          // :61, :84-85
                 q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
                 q.minL = lvl - 1; q.maxL = lvl;
-                q.xr = QS->f2[qi];
+                q.xr = QS.f2[qi];
             } else {
-                q.r = QS->f2[qi]; q.minL = QS->l0[qi]; q.maxL = QS->l1[qi];
-                if (QS->f3) q.xr = QS->f3[qi];
-                if (QS->angle) q.angle = QS->angle[qi];
+                q.r = QS.f2[qi]; q.minL = QS.l0[qi]; q.maxL = QS.l1[qi];
+                if (QS.f3) q.xr = QS.f3[qi];
+                if (QS.angle) q.angle = QS.angle[qi];
             }
         }
     }
@@ -157,8 +159,7 @@ __device__ __forceinline__ Query load_params(const WinParams &P, const FrameDev 
 
 template <int MODE>
 __device__ __forceinline__ void load_desc(const QSrc &S, int qi, Query &q) {
-    const uint32_t *dsrc = MODE == MODE_INIT ? S.F1->desc : S.QS->desc;
-    const uint4 *p4 = reinterpret_cast<const uint4 *>(dsrc) + 2 * (size_t)qi;
+    const gptr<const v4u> p4 = (gptr<const v4u>)(MODE == MODE_INIT ? S.F1.desc : S.QS.desc) + 2 * (size_t)qi;
     q.d0 = p4[0]; q.d1 = p4[1];
 }
 
@@ -177,7 +178,7 @@ __device__ __forceinline__ bool static_gates(const Query &q, bool stereo_gate, i
 
 template <int MODE>
 __device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
-    return MODE == MODE_PROJ || (MODE == MODE_LAST && S.QS->f3 != nullptr);
+    return MODE == MODE_PROJ || (MODE == MODE_LAST && S.QS.f3 != nullptr);
 }
 
 // ---- split form, kernel 1 of 2: ONE window walk per query, anywhere on the chip.  Nothing here depends on the slot
@@ -198,10 +199,10 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
     const int tid = threadIdx.x;
-    const FrameDev &F = P.frames[P.frame_ids[inst]];
+    const FrameG F(P.frames[P.frame_ids[inst]]);
     const int n = F.n;
     uint32_t *l_cell = lds;                                                      // 3076
-    float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);                      // 4n
+    v4f *l_rec = reinterpret_cast<v4f *>(lds + 3076);                            // 4n
     // skip lists (orbm_internal.h, cell_nxt): staged when the frame has them and the launch left room
     const bool have_nxt = stage_nxt && F.cell_nxt != nullptr;
     uint16_t *l_nxt = reinterpret_cast<uint16_t *>(lds + 3076 + 4 * (size_t)n);  // (n + 1) x 8
@@ -211,15 +212,15 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
     for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
     if (have_nxt) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(F.cell_nxt);
-        uint4 *l = reinterpret_cast<uint4 *>(l_nxt);
+        const gptr<const v4u> g = (gptr<const v4u>)F.cell_nxt;
+        v4u *l = reinterpret_cast<v4u *>(l_nxt);
         const int rows = (int)F.cell_off[ORBM_GRID_CELLS] + 1;
         for (int i = tid; i < rows; i += COLLECT_THREADS) l[i] = g[i];
     }
     __syncthreads();
     const QSrc S = query_source<MODE>(P, inst);
     const bool stereo_gate = has_stereo_gate<MODE>(S);
-    const uint4 *gdesc = reinterpret_cast<const uint4 *>(F.desc);
+    const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
     const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
     constexpr int WAVES = COLLECT_THREADS / 64;
     constexpr int SUPER = 2 * COLLECT_THREADS;      // queries sorted together: two rows of 64 per wave
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         int ncand = 0;      // candidates that passed the static gates
         auto finish = [&](uint32_t v) {                         // v = k | oct << 16 -> adds the distance, notes claimables
             const int k = (int)(v & 0xFFFFu);
-            const uint4 dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
+            const v4u dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
             const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
             const uint32_t dist = hamming256(qd, cd);
             if ((int)dist <= P.dist_th) {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             while (more) {
                 if (j < e) {
                     const uint32_t jcur = j;
-                    const float4 rc = l_rec[j];
+                    const v4f rc = l_rec[j];
                     j = hop ? (uint32_t)nx[(j + 1) * 8] : j + 1;
                     const uint32_t w = __float_as_uint(rc.w);
                     const int oct = (int)(w >> 16);
@@ -367,25 +368,25 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                               const uint64_t *postable_in, int cap, const uint32_t *cand_hi) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
-    const FrameDev &F = P.frames[P.frame_ids[inst]];
+    const FrameG F(P.frames[P.frame_ids[inst]]);
     const int n = F.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
     // LDS carve.  LDS_FRAME: [cell_off 3076][rec 4n][desc 8n] then the slot state; else slot state only.
-    FrameAcc acc;
+    FrameAccT<LDS_FRAME> acc;
     acc.min_x = F.min_x; acc.min_y = F.min_y; acc.inv_w = F.inv_w; acc.inv_h = F.inv_h;
     uint32_t *base = lds;
-    if (LDS_FRAME) {
+    if constexpr (LDS_FRAME) {
         uint32_t *l_cell = lds;
-        float4 *l_rec = reinterpret_cast<float4 *>(lds + 3076);
-        uint4 *l_desc = reinterpret_cast<uint4 *>(lds + 3076 + 4 * (size_t)n);
+        v4f *l_rec = reinterpret_cast<v4f *>(lds + 3076);
+        v4u *l_desc = reinterpret_cast<v4u *>(lds + 3076 + 4 * (size_t)n);
         for (int i = tid; i <= ORBM_GRID_CELLS; i += nthr) l_cell[i] = F.cell_off[i];
         for (int i = tid; i < n; i += nthr) l_rec[i] = F.cell_rec[i];
-        const uint4 *gd = reinterpret_cast<const uint4 *>(F.desc);
+        const gptr<const v4u> gd = (gptr<const v4u>)F.desc;
         for (int i = tid; i < 2 * n; i += nthr) l_desc[i] = gd[i];
         acc.cell_off = l_cell; acc.rec = l_rec; acc.desc = l_desc;
         base = lds + 3076 + 12 * (size_t)n;
     } else {
-        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = reinterpret_cast<const uint4 *>(F.desc);
+        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = (gptr<const v4u>)F.desc;
     }
     uint32_t *state = base;                       // ORBM_MP_* flags | vMatchedDistance
     int32_t *owner = (int32_t *)(base + n);
@@ -396,8 +397,6 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     int *keep = hist + 33;
 
     const QSrc S = query_source<MODE>(P, inst);
-    const QSetDev *QS = S.QS;
-    const FrameDev *F1 = S.F1;
     const int Q = S.Q;
     int32_t *out = P.out + (size_t)inst * P.stride;
 
@@ -416,7 +415,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     __syncthreads();
 
     const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
-                          (MODE == MODE_INIT || QS->angle != nullptr);
+                          (MODE == MODE_INIT || S.QS.angle != nullptr);
     const bool stereo_gate = has_stereo_gate<MODE>(S);
     const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
@@ -465,7 +464,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             auto collect = [&](int k, int oct, float ur) {
                 if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                 if (ncand < WIN_CACHE) {
-                    const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                    const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                     const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     const uint32_t v = (uint32_t)k | ((uint32_t)oct << 16) | (hamming256(qd, cd) << 20);
 #pragma unroll
@@ -544,7 +543,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 } else {
                     auto body = [&](int k, int oct, float ur) {
                         if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
-                        const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                        const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                         const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                         consider(k, oct, (int)hamming256(qd, cd));
                     };
@@ -582,7 +581,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                         auto body = [&](int k, int oct, float ur) {
                             if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                             if (MODE == MODE_INIT) {
-                                const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+                                const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                                 const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                                 if (is_blocked(state[k], (int)hamming256(qd, cd))) return;
                             } else if (is_blocked(state[k], 0)) return;
@@ -749,7 +748,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             for (int i = tid; i < Q; i += nthr) {
                 const int m = out[i];
                 if (m < 0) continue;                                                      // :673 (a stolen match is already -1)
-                const int bin = rot_bin(F1->angle[i], F.angle[m]);
+                const int bin = rot_bin(S.F1.angle[i], F.angle[m]);
                 if (!((keepmask >> bin) & 1u)) { out[i] = -1; removed++; }
             }
             if (removed) atomicSub(nmatch, removed);
@@ -775,21 +774,21 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
 __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_inst, int chi2_gate) {
     const int inst = blockIdx.x / chunks_per_inst;
     const int chunk = blockIdx.x - inst * chunks_per_inst;
-    const FrameDev &F = P.frames[P.frame_ids[inst]];
-    const QSetDev &QS = P.qsets[P.qset_ids[inst]];
+    const FrameG F(P.frames[P.frame_ids[inst]]);
+    const QSetG QS(P.qsets[P.qset_ids[inst]]);
     const int qi = chunk * 256 + (int)threadIdx.x;
     if (qi >= QS.n || qi >= P.stride) return;
     int32_t *out = P.out + (size_t)inst * P.stride;
     int result = -1;
     if (QS.flags[qi] & ORBM_Q_VALID) {
-        FrameAcc acc;
+        FrameAccT<false> acc;
         acc.min_x = F.min_x; acc.min_y = F.min_y; acc.inv_w = F.inv_w; acc.inv_h = F.inv_h;
-        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = reinterpret_cast<const uint4 *>(F.desc);
+        acc.cell_off = F.cell_off; acc.rec = F.cell_rec; acc.desc = (gptr<const v4u>)F.desc;
         const float u = QS.f0[qi], v = QS.f1[qi], radius = QS.f2[qi];
         const float ur = QS.f3 ? QS.f3[qi] : 0.f;
         const int minL = QS.l0[qi], maxL = QS.l1[qi];
-        const uint4 *p4 = reinterpret_cast<const uint4 *>(QS.desc) + 2 * (size_t)qi;
-        const uint4 d0 = p4[0], d1 = p4[1];
+        const gptr<const v4u> p4 = (gptr<const v4u>)QS.desc + 2 * (size_t)qi;
+        const v4u d0 = p4[0], d1 = p4[1];
         const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         int bestDist = INT_MAX, bestIdx = -1;
         auto body = [&](int k, int oct, float kur) {
@@ -806,7 +805,7 @@ __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_i
                     if ((double)__fmul_rn(e2, inv) > 5.99) return;
                 }
             }
-            const uint4 lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
+            const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
             const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const int dist = (int)hamming256(qd, cd);
             if (dist < bestDist) { bestDist = dist; bestIdx = k; }
