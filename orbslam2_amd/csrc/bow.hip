@@ -472,7 +472,34 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
             auto note = [&](uint32_t d, uint32_t t) {
                 if (MODE == 2) update(d, t, best, second); else update4(d, t, best, second, third, fourth);
             };
-            if (staged) {
+            if (staged && MODE != 2) {
+                // no branches and no masked lanes inside: a lane past the end of its node (or without a query) reads its
+                // last row again and inserts a key that sorts after everything; the next candidate's row is read from LDS
+                // while this one is compared
+                const int tmax = wave_max(qvalid ? (int)mNB : 0);
+                const uint32_t tlast = mNB ? mNB - 1 : 0;
+                const uint4 *rowp = w_rows + 2 * my_cbase;
+                const uint32_t *metap = w_meta + my_cbase;
+                auto step = [&](uint32_t t, const uint4 &lo, const uint4 &hi, uint32_t m) {
+                    const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    bool ok = qvalid && t < mNB;
+                    if (MODE == 1) ok = ok && ((m >> 16) & (ORBM_MP_PRESENT | ORBM_MP_BAD)) == ORBM_MP_PRESENT;   // :766-770
+                    const uint32_t d = hamming256(q, cd);
+                    uint32_t x = ok ? (d << 16) | t : 0xFFFFFFFFu, lo4;
+                    lo4 = min(best, x); x = max(best, x); best = lo4;
+                    lo4 = min(second, x); x = max(second, x); second = lo4;
+                    lo4 = min(third, x); x = max(third, x); third = lo4;
+                    fourth = min(fourth, x);
+                };
+                // two candidates per pass: the LDS reads of the second are in flight while the first is compared
+                for (int t = 0; t < tmax; t += 2) {
+                    const uint32_t t0 = min((uint32_t)t, tlast), t1 = min((uint32_t)t + 1u, tlast);
+                    const uint4 lo0 = rowp[2 * t0], hi0 = rowp[2 * t0 + 1], lo1 = rowp[2 * t1], hi1 = rowp[2 * t1 + 1];
+                    const uint32_t m0 = metap[t0], m1 = metap[t1];
+                    step((uint32_t)t, lo0, hi0, m0);
+                    step((uint32_t)t + 1u, lo1, hi1, m1);
+                }
+            } else if (staged) {
                 const int tmax = wave_max(qvalid ? (int)mNB : 0);
                 for (int t = 0; t < tmax; t++) {
                     if (qvalid && (uint32_t)t < mNB) {
