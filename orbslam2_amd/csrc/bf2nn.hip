@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
 // v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0): K = 64 per instruction at the cycles of the bf16 32x32 form, so a
 // tile of 1024 distances is 4 instructions instead of 8, and every staged byte carries two bit positions.  (The 16x16x128
 // shape of the same instruction was measured 12 % slower here, 8-wave workgroups and register-prefetched stages no
-// faster.)  Products are
+// faster; scripts/ubench_mfma4*.hip: what the chip sustains on this instruction and what each ingredient of this loop costs.)  Products are
 // +-1 and the f32 sums are integers of magnitude <= 256: exact.  Lane l supplies bytes [32 s + 16 h, + 16) of row l & 31
 // for k step s (32 values), for A and B alike.  C/D layout and everything after the product as in the int8 form.
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -403,7 +403,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     int stage = 0;
     for (int c0 = 0; c0 < nB8; c0 += HALF, stage ^= 1) {
         const int rows = min(HALF, nB8 - c0);               // a multiple of 32
-        __syncthreads();                                    // stage `stage` has landed (vmcnt(0) precedes the barrier); the other buffer is free
+        // this wave's part of stage `stage` has landed: LDS-DMA loads count on vmcnt, which the barrier's own fence does
+        // not wait for (it covers LDS instructions only); they were issued a whole stage ago, so the wait costs nothing
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+        __syncthreads();                                    // every wave's part has: the stage is complete, the other buffer is free
         if (DIAG != 2 && c0 + HALF < nB8) issue_stage(c0 + HALF, stage ^ 1);
         const v4i *tbuf = tile + (DIAG == 2 ? 0 : stage) * (HALF * 8);
         for (int rb = 0; rb < rows; rb += 32) {
