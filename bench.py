@@ -392,7 +392,9 @@ def main():
                                  "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz; "
                                  "the chip holds about 1.5-2.0 GHz in MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back). "
                                  "vs_integer_popcount_roofline = achieved cmps/s over the 3.277 T cmps/s that bound the xor + popcount "
-                                 "form of this kernel (roofline_popcount_form: that form, same workload, same run)"},
+                                 "form of this kernel (roofline_popcount_form: that form, same workload, same run). scripts/ubench_mfma4*.hip "
+                                 "(profiles/r01_ubench_mfma4.txt): back-to-back MFMAs on +-1 operands sustain 0.75-0.85 of this peak "
+                                 "(power), this kernel's loop structure in isolation 0.54"},
         }
         res["roofline"]["vs_integer_popcount_roofline"] = round(achieved_tcmps / PEAK_TCMPS, 3)
         try:
