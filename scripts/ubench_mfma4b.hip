@@ -2,7 +2,7 @@
 // MODE bits: 1 = A fragments read from LDS (4 x ds_read_b128 per 8 MFMAs), 2 = the v_max3 fold of both result tiles,
 // 4 = one s_barrier per 32 MFMAs, 8 = staging of the next 128 candidate rows (16 KB) per pass with global_load_lds,
 // 16 = staged from a 64 KB region instead of a 16 MB one, 64 = no vmcnt wait before the barrier, 128 = staging through
-// registers, 256 = one staging load per row tile instead of all at the top, 512 = raw bits + expansion (see main).
+// registers, 256 = one staging load per row tile instead of all at the top, 512 = raw bits + expansion, 1024 = lanes read consecutive chunks, 2048 = scalar base + 32-bit lane offset (see main).
 // Build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o ubench_mfma4b ubench_mfma4b.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void k(int iters, float *sink, unsigned long l
             // the product kernel's staging: 128 rows x 128 B per pass, into the buffer not being read
             const int g0 = __builtin_amdgcn_readfirstlane((wave * 4 + j) * 64);
             const int g = g0 + lane, r = g >> 3, cpos = g & 7;
-            const v4i *src = src0 + r * 8 + (cpos ^ ((r >> 1) & 7));
+            const uint32_t blk_off = __builtin_amdgcn_readfirstlane((blk & ((MODE & 16) ? 3u : 1023u)) * 1024u);
+            const v4i *src = (MODE & 2048) ? store + (blk_off + (uint32_t)(r * 8 + (cpos ^ ((r >> 1) & 7)))) : src0 + r * 8 + ((MODE & 1024) ? cpos : (cpos ^ ((r >> 1) & 7)));
             if (MODE & 128) stg[j] = *(const __attribute__((address_space(1))) v4i *)src;      // to registers, written to LDS at the end of the pass
             else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                   (__attribute__((address_space(3))) void *)(tile + ((it + 1) & 1) * 1024 + g0), 16, 0, 0);
@@ -129,7 +130,7 @@ int run(int wgs_per_cu, float *sink, unsigned long long *clk, const v4i *store) 
     const double mfma = (double)grid * 4 * iters * 32;
     const double tflops = mfma * 2.0 * 32 * 32 * 64 / (ms * 1e-3) / 1e12;
     const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9;
-    printf("%d loads/pass, LDS %d KB, mode %d%s%s%s (%s%s%s), %d waves/SIMD: %.1f ms, %.0f TFLOP/s (%.3f of 10066), clock %.2f GHz, %.1f cycles per MFMA per SIMD\n", NLD, LDSV4 / 64, MODE, (MODE & 64) ? " nowait" : "", (MODE & 128) ? " via-registers" : "", (MODE & 512) ? " raw-bits+expand" : (MODE & 256) ? " spread" : "",
+    printf("%d loads/pass, LDS %d KB, mode %d%s%s%s (%s%s%s), %d waves/SIMD: %.1f ms, %.0f TFLOP/s (%.3f of 10066), clock %.2f GHz, %.1f cycles per MFMA per SIMD\n", NLD, LDSV4 / 64, MODE, (MODE & 64) ? " nowait" : "", (MODE & 128) ? " via-registers" : "", (MODE & 2048) ? " saddr" : (MODE & 1024) ? " linear-global" : (MODE & 512) ? " raw-bits+expand" : (MODE & 256) ? " spread" : "",
            (MODE & 1) ? "lds " : "", (MODE & 2) ? "fold " : "", (MODE & 4) ? ((MODE & 8) ? ((MODE & 16) ? ((MODE & 32) ? "barrier staging-small-half" : "barrier staging-small") : ((MODE & 32) ? "barrier staging-half" : "barrier staging")) : "barrier") : "", wgs_per_cu, ms, tflops, tflops / 10066.3, ghz,
            (double)h[0] / (32.0 * iters * wgs_per_cu));
     return 0;
@@ -149,7 +150,9 @@ int main() {
         run<15, 2048, 4>(w, sink, clk, store) ||           //   = the product kernel's inner loop
         run<31, 2048, 4>(w, sink, clk, store) ||           //   the same from a 64 KB region (L2 hits)
         run<15 + 128, 2048, 4>(w, sink, clk, store) ||     //   through registers + ds_write_b128 instead
-        run<7 + 512, 2048, 0>(w, sink, clk, store))        //   raw descriptor bits (1 load) expanded to FP4 by the vector ALU
+        run<7 + 512, 2048, 0>(w, sink, clk, store) ||      //   raw descriptor bits (1 load) expanded to FP4 by the vector ALU
+        run<15 + 1024, 2048, 4>(w, sink, clk, store) ||    //   lanes read consecutive 16-byte chunks (no swizzle on the global side)
+        run<15 + 2048, 2048, 4>(w, sink, clk, store))      //   scalar base + 32-bit lane offset addressing
         return 1;
     return 0;
 }
