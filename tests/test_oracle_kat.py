@@ -178,6 +178,265 @@ def test_oracle_bow_against_numpy_restatement(orc, variant):
     assert cnt == nm and np.array_equal(m, match)
 
 
+def _numpy_grid(F):
+    """Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:278-298, 506-519): round(), not floor; insertion order = index order."""
+    f32 = np.float32
+    min_x, min_y, max_x, max_y = (f32(v) for v in F.bounds)
+    inv_w, inv_h = f32(f32(64) / f32(max_x - min_x)), f32(f32(48) / f32(max_y - min_y))
+    rnd = lambda v: int(np.copysign(np.floor(abs(float(v)) + 0.5), float(v)))          # C round(): halves away from zero
+    grid = {}
+    for i in range(F.n):
+        px, py = rnd(f32(f32(F.x[i] - min_x) * inv_w)), rnd(f32(f32(F.y[i] - min_y) * inv_h))
+        if 0 <= px < 64 and 0 <= py < 48:
+            grid.setdefault((px, py), []).append(i)
+    return grid, (min_x, min_y, inv_w, inv_h)
+
+
+def _numpy_features_in_area(F, grid, geo, x, y, r, min_level, max_level):
+    """Frame::GetFeaturesInArea, Frame.cc:434-498."""
+    f32 = np.float32
+    min_x, min_y, inv_w, inv_h = geo
+    x, y, r = f32(x), f32(y), f32(r)
+    c0x = max(0, int(np.floor(f32(f32(f32(x - min_x) - r) * inv_w))))
+    if c0x >= 64:
+        return []
+    c1x = min(63, int(np.ceil(f32(f32(f32(x - min_x) + r) * inv_w))))
+    if c1x < 0:
+        return []
+    c0y = max(0, int(np.floor(f32(f32(f32(y - min_y) - r) * inv_h))))
+    if c0y >= 48:
+        return []
+    c1y = min(47, int(np.ceil(f32(f32(f32(y - min_y) + r) * inv_h))))
+    if c1y < 0:
+        return []
+    check = min_level > 0 or max_level >= 0
+    out = []
+    for ix in range(c0x, c1x + 1):
+        for iy in range(c0y, c1y + 1):
+            for i in grid.get((ix, iy), []):
+                if check:
+                    if F.octave[i] < min_level:
+                        continue
+                    if max_level >= 0 and F.octave[i] > max_level:
+                        continue
+                if abs(f32(F.x[i] - x)) < r and abs(f32(F.y[i] - y)) < r:
+                    out.append(i)
+    return out
+
+
+def _numpy_search_proj_points(F, Q, th, ratio):
+    """Slow, independent restatement of SearchByProjection(Frame&, vector<MapPoint*>&, th), ORBmatcher.cc:57-176:
+    returns (nmatches, owner per keypoint = index of the map point written into F.mvpMapPoints last, -1 = untouched)."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    grid, geo = _numpy_grid(F)
+    present = (F.mp_flags & MP_PRESENT) != 0 if F.mp_flags is not None else np.zeros(F.n, bool)
+    observed = (F.mp_flags & MP_OBS) != 0 if F.mp_flags is not None else np.zeros(F.n, bool)
+    present, observed = present.copy(), observed.copy()
+    owner = np.full(F.n, -1, np.int64)
+    nmatches = 0
+    for q in range(Q.desc.shape[0]):
+        if not (Q.flags[q] & Q_VALID):                                     # mbTrackInView && !isBad()
+            continue
+        lvl = int(Q.level[q])
+        r = f32(2.5) if Q.view_cos[q] > f32(0.998) else f32(4.0)
+        if f32(th) != f32(1.0):
+            r = f32(r * f32(th))
+        rr = f32(r * F.scale_factors[lvl])
+        idx = _numpy_features_in_area(F, grid, geo, Q.proj_x[q], Q.proj_y[q], rr, lvl - 1, lvl)
+        if not idx:
+            continue
+        bd, bl, bd2, bl2, bi = 256, -1, 256, -1, -1
+        for i in idx:
+            if present[i] and observed[i]:
+                continue
+            if F.uright is not None and F.uright[i] > 0:
+                if abs(f32(Q.proj_xr[q] - F.uright[i])) > rr:
+                    continue
+            d = ham(Q.desc[q], F.desc[i])
+            if d < bd:
+                bd2, bd, bl2, bl, bi = bd, d, bl, int(F.octave[i]), i
+            elif d < bd2:
+                bl2, bd2 = int(F.octave[i]), d
+        if bd <= 100:
+            if bl == bl2 and f32(bd) > f32(ratio) * f32(bd2):
+                continue
+            present[bi] = True
+            observed[bi] = bool(Q.flags[q] & Q_OBS)
+            owner[bi] = q
+            nmatches += 1
+    return nmatches, owner
+
+
+@pytest.mark.parametrize("th,stereo", [(1.0, False), (3.0, False), (3.0, True)])
+def test_oracle_proj_points_against_numpy_restatement(orc, th, stereo):
+    f, q = synth.proj_instance(seed=777 + int(th), n=300, n_queries=1500, stereo=stereo, claimed_frac=0.2, obs_frac=0.8, valid_frac=0.95)
+    nm, owner = _numpy_search_proj_points(f, q, th, 0.8)
+    cnt, wo, _ = orc.search_proj_points(f, q, th, 0.8)
+    assert nm > 100 and cnt == nm and np.array_equal(wo, owner)
+
+
+def _numpy_search_init(F1, F2, prev, window, ratio, check_ori):
+    """Slow, independent restatement of SearchForInitialization, ORBmatcher.cc:562-688."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    grid, geo = _numpy_grid(F2)
+    m12 = np.full(F1.n, -1, np.int64)
+    m21 = np.full(F2.n, -1, np.int64)
+    mdist = np.full(F2.n, np.iinfo(np.int32).max, np.int64)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for i1 in range(F1.n):
+        if F1.octave[i1] > 0:
+            continue
+        idx = _numpy_features_in_area(F2, grid, geo, prev[i1, 0], prev[i1, 1], window, 0, 0)
+        if not idx:
+            continue
+        bd, bd2, bi = np.iinfo(np.int32).max, np.iinfo(np.int32).max, -1
+        for i2 in idx:
+            d = ham(F1.desc[i1], F2.desc[i2])
+            if mdist[i2] <= d:
+                continue
+            if d < bd:
+                bd2, bd, bi = bd, d, i2
+            elif d < bd2:
+                bd2 = d
+        if bd <= 50 and f32(bd) < f32(f32(bd2) * f32(ratio)):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                nm -= 1
+            m12[i1] = bi; m21[bi] = i1; mdist[bi] = bd
+            nm += 1
+            if check_ori:
+                rot = f32(F1.angle[i1]) - f32(F2.angle[bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360.0))
+                b = int(np.floor(f32(rot * f32(1.0 / 30)) + 0.5))
+                hist[0 if b == 30 else b].append(i1)
+    return nm, m12, hist
+
+
+@pytest.mark.parametrize("ratio", [0.9, 0.99])
+def test_oracle_search_init_against_numpy_restatement(orc, ratio):
+    rng = np.random.default_rng(31 + int(ratio * 100))
+    lm = synth.random_descriptors(rng, 40)
+    mk = lambda n: synth.make_frame(rng, lm, rng.integers(0, 40, n), x=rng.uniform(250, 330, n).astype(np.float32),
+                                    y=rng.uniform(200, 280, n).astype(np.float32), octave=np.where(rng.random(n) < 0.8, 0, 1).astype(np.int32),
+                                    p_flip=0.08, with_fv=False)
+    f1, f2 = mk(160), mk(120)
+    prev = np.stack([f1.x, f1.y], 1).astype(np.float32)
+    nm, m12, hist = _numpy_search_init(f1, f2, prev, 100, ratio, True)
+    keep = orc.three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in keep:
+            for i1 in hist[b]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nm -= 1
+    want_prev = prev.copy()
+    for i1 in range(f1.n):
+        if m12[i1] >= 0:
+            want_prev[i1] = (f2.x[m12[i1]], f2.y[m12[i1]])
+    cnt, wm, wprev, _ = orc.search_init(f1, f2, prev, 100, ratio, True)
+    assert cnt == nm and np.array_equal(wm, m12) and np.array_equal(wprev, want_prev) and nm > 5
+
+
+def _numpy_search_triang(A, B, F12, epipole, only_stereo, check_ori):
+    """Slow, independent restatement of SearchForTriangulation, ORBmatcher.cc:868-1093 (F12 row-major 3x3, epipole = (ex, ey));
+    note that vbMatched2 is read but never set there, so a KF2 keypoint may be matched by several KF1 keypoints."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    F = np.asarray(F12, np.float32).reshape(3, 3)
+    ex, ey = f32(epipole[0]), f32(epipole[1])
+
+    def epi_ok(i1, i2):                                                   # CheckDistEpipolarLine, :179-206
+        x1, y1, x2, y2 = A.x[i1], A.y[i1], B.x[i2], B.y[i2]
+        a = f32(f32(f32(x1 * F[0, 0]) + f32(y1 * F[1, 0])) + F[2, 0])
+        b = f32(f32(f32(x1 * F[0, 1]) + f32(y1 * F[1, 1])) + F[2, 1])
+        c = f32(f32(f32(x1 * F[0, 2]) + f32(y1 * F[1, 2])) + F[2, 2])
+        num = f32(f32(f32(a * x2) + f32(b * y2)) + c)
+        den = f32(f32(a * a) + f32(b * b))
+        if den == 0:
+            return False
+        dsqr = f32(f32(num * num) / den)
+        return float(dsqr) < 3.84 * float(B.level_sigma2[B.octave[i2]])
+
+    match = np.full(A.n, -1, np.int64)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    nodesB = {int(n): k for k, n in enumerate(B.fv_node)}
+    for ka, node in enumerate(A.fv_node):
+        kb = nodesB.get(int(node))
+        if kb is None:
+            continue
+        for i1 in A.fv_idx[A.fv_off[ka]:A.fv_off[ka + 1]]:
+            if A.mp_flags[i1] & MP_PRESENT:
+                continue
+            st1 = A.uright[i1] >= 0
+            if only_stereo and not st1:
+                continue
+            bd, bi = 50, -1
+            for i2 in B.fv_idx[B.fv_off[kb]:B.fv_off[kb + 1]]:
+                if B.mp_flags[i2] & MP_PRESENT:
+                    continue
+                st2 = B.uright[i2] >= 0
+                if only_stereo and not st2:
+                    continue
+                d = ham(A.desc[i1], B.desc[i2])
+                if d > 50 or d > bd:
+                    continue
+                if not st1 and not st2:
+                    dx, dy = f32(ex - B.x[i2]), f32(ey - B.y[i2])
+                    if f32(f32(dx * dx) + f32(dy * dy)) < f32(f32(100) * B.scale_factors[B.octave[i2]]):
+                        continue
+                if epi_ok(i1, i2):
+                    bi, bd = int(i2), d
+            if bi >= 0:
+                match[i1] = bi
+                nm += 1
+                if check_ori:
+                    rot = f32(A.angle[i1]) - f32(B.angle[bi])
+                    if rot < 0:
+                        rot = f32(rot + f32(360.0))
+                    b = int(np.floor(f32(rot * f32(1.0 / 30)) + 0.5))
+                    hist[0 if b == 30 else b].append(int(i1))
+    return nm, match, hist
+
+
+@pytest.mark.parametrize("only_stereo", [False, True])
+def test_oracle_triang_against_numpy_restatement(orc, only_stereo):
+    A, B, f12, ep = synth.triang_pair(61, n=1500 if only_stereo else 400)[:4]
+    nm, match, hist = _numpy_search_triang(A, B, f12, ep, only_stereo, True)
+    keep = orc.three_maxima([len(h) for h in hist])
+    for b in range(30):
+        if b not in keep:
+            for i1 in hist[b]:
+                match[i1] = -1
+                nm -= 1
+    cnt, wm, _ = orc.search_triang(A, B, f12, ep, only_stereo, True)
+    assert cnt == nm and np.array_equal(wm, match) and nm > (2 if only_stereo else 20)
+
+
+def test_oracle_bf2nn_against_numpy_restatement(orc):
+    """Brute-force 2-NN + TH_LOW + ratio test (SearchByBoW's inner loop over one node holding everything, ORBmatcher.cc:271-312
+    without the claims): all distances with numpy, first index wins ties."""
+    rng = np.random.default_rng(99)
+    lm = synth.random_descriptors(rng, 80)
+    mk = lambda n: synth.make_frame(rng, lm, rng.integers(0, 80, n), p_flip=0.1, with_fv=False)
+    A, B = mk(120), mk(150)
+    D = np.unpackbits(A.desc[:, None, :] ^ B.desc[None, :, :], axis=2).sum(axis=2).astype(np.int64)
+    cnt, match, bd, sd, ncmp = orc.bf2nn(A, B, 0.75, 50)
+    assert ncmp == 120 * 150
+    want_cnt = 0
+    for i in range(A.n):
+        order = np.argsort(D[i], kind="stable")                           # first index among equal distances
+        b1, b2, bi = int(D[i, order[0]]), int(D[i, order[1]]), int(order[0])
+        ok = b1 <= 50 and np.float32(b1) < np.float32(0.75) * np.float32(b2)
+        assert bd[i] == b1 and sd[i] == b2 and match[i] == (bi if ok else -1), i
+        want_cnt += ok
+    assert cnt == want_cnt and cnt > 10
+
+
 def test_oracle_proj_claims_known_answer(orc):
     """Two map points project onto the same keypoint: the first (with observations) claims it, the second
     must skip it (ORBmatcher.cc:113-115) and take the other keypoint in its window."""
