@@ -417,6 +417,88 @@ def test_oracle_triang_against_numpy_restatement(orc, only_stereo):
     assert cnt == nm and np.array_equal(wm, match) and nm > (2 if only_stereo else 20)
 
 
+def _numpy_search_window(mode, F, Q, dist_th, check_ori):
+    """Slow, independent restatement of the best-1 windowed inner loops on pre-projected queries: mode 0 =
+    SearchByProjection(CurrentFrame, LastFrame) ORBmatcher.cc:1845-1947, mode 1 = SearchByProjection(CurrentFrame, KeyFrame*)
+    :2026-2120, mode 2 = SearchByProjection(KeyFrame*, Scw) :495-537 (KeyFrame::GetFeaturesInArea: no level filter, the level
+    test comes after the matched-slot test).  owner: -1 untouched, -2 written and then set to NULL by the rotation filter."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    grid, geo = _numpy_grid(F)
+    flags = F.mp_flags if F.mp_flags is not None else np.zeros(F.n, np.uint8)
+    present, observed = (flags & MP_PRESENT) != 0, (flags & MP_OBS) != 0
+    owner = np.full(F.n, -1, np.int64)
+    hist = [[] for _ in range(30)]
+    use_hist = check_ori and mode != 2 and Q.angle is not None
+    nm = 0
+    for q in range(Q.desc.shape[0]):
+        if not (Q.flags[q] & Q_VALID):
+            continue
+        lo, hi = int(Q.min_level[q]), int(Q.max_level[q])
+        idx = _numpy_features_in_area(F, grid, geo, Q.u[q], Q.v[q], Q.radius[q], -1 if mode == 2 else lo, -1 if mode == 2 else hi)
+        if not idx:
+            continue
+        bd, bi = 256, -1
+        for i in idx:
+            if mode == 0:
+                if present[i] and observed[i]:
+                    continue
+                if Q.ur is not None and F.uright is not None and F.uright[i] > 0:
+                    if abs(f32(Q.ur[q] - F.uright[i])) > Q.radius[q]:
+                        continue
+            else:
+                if present[i]:
+                    continue
+                if mode == 2 and (F.octave[i] < lo or F.octave[i] > hi):
+                    continue
+            d = ham(Q.desc[q], F.desc[i])
+            if d < bd:
+                bd, bi = d, i
+        if bd <= dist_th:
+            present[bi] = True
+            observed[bi] = True if mode != 0 else bool(Q.flags[q] & Q_OBS)
+            owner[bi] = q
+            nm += 1
+            if use_hist:
+                rot = f32(Q.angle[q]) - f32(F.angle[bi])
+                if rot < 0:
+                    rot = f32(rot + f32(360.0))
+                b = int(np.floor(f32(rot * f32(1.0 / 30)) + 0.5))
+                hist[0 if b == 30 else b].append(bi)
+    return nm, owner, hist
+
+
+@pytest.mark.parametrize("mode,dist_th", [(0, 100), (1, 90), (2, 50)])
+def test_oracle_search_window_against_numpy_restatement(orc, mode, dist_th):
+    from orbslam2_amd.views import WinQueries
+    rng = np.random.default_rng(500 + mode)
+    n, nq = 120, 500
+    lm = synth.random_descriptors(rng, 30)
+    lmi = rng.integers(0, 30, n)
+    f = synth.make_frame(rng, lm, lmi, x=rng.uniform(200, 320, n).astype(np.float32), y=rng.uniform(200, 300, n).astype(np.float32),
+                         octave=rng.integers(1, 5, n).astype(np.int32), p_flip=0.03, with_fv=False,
+                         mp_flags=np.where(rng.random(n) < 0.15, MP_PRESENT | MP_OBS, 0).astype(np.uint8))
+    src = rng.integers(0, n, nq)
+    desc = np.stack([synth.observe(rng, lm[lmi[s]][None, :], p)[0] for s, p in zip(src, rng.choice([0.05, 0.2, 0.3, 0.4], nq))])
+    q = WinQueries(desc=desc, u=(f.x[src] + rng.normal(0, 6, nq)).astype(np.float32), v=(f.y[src] + rng.normal(0, 6, nq)).astype(np.float32),
+                   radius=rng.uniform(10, 40, nq).astype(np.float32), min_level=(f.octave[src] - 1).astype(np.int32),
+                   max_level=np.where(rng.random(nq) < 0.2, -1, f.octave[src] + 1).astype(np.int32), ur=None,
+                   angle=rng.uniform(0, 360, nq).astype(np.float32),
+                   flags=(np.where(rng.random(nq) < 0.95, Q_VALID, 0) | np.where(rng.random(nq) < 0.7, Q_OBS, 0)).astype(np.uint8))
+    if mode == 2:
+        q.max_level = np.maximum(q.max_level, q.min_level).astype(np.int32)   # the Sim3 overload always has both bounds
+    nm, owner, hist = _numpy_search_window(mode, f, q, dist_th, True)
+    if mode != 2:
+        keep = orc.three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b not in keep:
+                for bi in hist[b]:
+                    owner[bi] = -2
+                    nm -= 1
+    cnt, wo, _ = orc.search_window(mode, f, q, dist_th, True)
+    assert cnt == nm and np.array_equal(wo, owner) and (owner >= 0).sum() > 10
+
+
 def test_oracle_bf2nn_against_numpy_restatement(orc):
     """Brute-force 2-NN + TH_LOW + ratio test (SearchByBoW's inner loop over one node holding everything, ORBmatcher.cc:271-312
     without the claims): all distances with numpy, first index wins ties."""
