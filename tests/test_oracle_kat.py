@@ -499,6 +499,127 @@ def test_oracle_search_window_against_numpy_restatement(orc, mode, dist_th):
     assert cnt == nm and np.array_equal(wo, owner) and (owner >= 0).sum() > 10
 
 
+def _numpy_search_window_free(F, Q, dist_th, chi2_gate):
+    """Slow, independent restatement of the claim-free best-1 inner loops: Fuse, ORBmatcher.cc:1185-1257 (chi-square gates
+    7.8 / 5.99 on mvInvLevelSigma2 = 1 / mvLevelSigma2) and :1390-1421, SearchBySim3 :1586-1626 (no gate)."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    grid, geo = _numpy_grid(F)
+    best = np.full(Q.desc.shape[0], -1, np.int64)
+    for q in range(Q.desc.shape[0]):
+        if not (Q.flags[q] & Q_VALID):
+            continue
+        u, v = f32(Q.u[q]), f32(Q.v[q])
+        bd, bi = 256, -1
+        for i in _numpy_features_in_area(F, grid, geo, u, v, Q.radius[q], -1, -1):      # KeyFrame::GetFeaturesInArea: no level filter
+            lvl = int(F.octave[i])
+            if lvl < Q.min_level[q] or lvl > Q.max_level[q]:
+                continue
+            if chi2_gate:
+                inv = f32(f32(1.0) / F.level_sigma2[lvl])
+                ex, ey = f32(u - F.x[i]), f32(v - F.y[i])
+                if F.uright is not None and F.uright[i] >= 0:
+                    er = f32(Q.ur[q] - F.uright[i])
+                    e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                    if float(f32(e2 * inv)) > 7.8:
+                        continue
+                else:
+                    e2 = f32(f32(ex * ex) + f32(ey * ey))
+                    if float(f32(e2 * inv)) > 5.99:
+                        continue
+            d = ham(Q.desc[q], F.desc[i])
+            if d < bd:
+                bd, bi = d, i
+        if bd <= dist_th:
+            best[q] = bi
+    return best
+
+
+@pytest.mark.parametrize("chi2,stereo", [(False, False), (True, False), (True, True)])
+def test_oracle_search_window_free_against_numpy_restatement(orc, chi2, stereo):
+    from orbslam2_amd.views import WinQueries
+    rng = np.random.default_rng(700 + 2 * chi2 + stereo)
+    n, nq = 150, 600
+    lm = synth.random_descriptors(rng, 40)
+    lmi = rng.integers(0, 40, n)
+    ur = np.where(rng.random(n) < 0.6, rng.uniform(1, 600, n), -1.0).astype(np.float32) if stereo else None
+    f = synth.make_frame(rng, lm, lmi, x=rng.uniform(200, 320, n).astype(np.float32), y=rng.uniform(200, 300, n).astype(np.float32),
+                         octave=rng.integers(0, 6, n).astype(np.int32), p_flip=0.03, with_fv=False, uright=ur)
+    src = rng.integers(0, n, nq)
+    desc = np.stack([synth.observe(rng, lm[lmi[s]][None, :], p)[0] for s, p in zip(src, rng.choice([0.05, 0.15, 0.25], nq))])
+    q = WinQueries(desc=desc, u=(f.x[src] + rng.normal(0, 2.5, nq)).astype(np.float32), v=(f.y[src] + rng.normal(0, 2.5, nq)).astype(np.float32),
+                   radius=rng.uniform(5, 25, nq).astype(np.float32), min_level=(f.octave[src] - 1).astype(np.int32),
+                   max_level=f.octave[src].astype(np.int32),
+                   ur=(f.uright[src] + rng.normal(0, 2.0, nq)).astype(np.float32) if stereo else np.zeros(nq, np.float32), angle=None,
+                   flags=np.where(rng.random(nq) < 0.95, Q_VALID | Q_OBS, 0).astype(np.uint8))
+    want = _numpy_search_window_free(f, q, 50, chi2)
+    got, _ = orc.search_window_free(f, q, 50, chi2)
+    assert np.array_equal(got, want) and (want >= 0).sum() > 50
+
+
+def _numpy_stereo_match(L, R, n_rows, max_d):
+    """Slow, independent restatement of the row table and descriptor stage of Frame::ComputeStereoMatches, Frame.cc:632-715
+    (row bands clipped to the table; best index -1 and distance TH_HIGH when nothing beats TH_HIGH)."""
+    f32 = np.float32
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    rows = [[] for _ in range(n_rows)]
+    for ir in range(R.n):
+        r = f32(f32(2.0) * R.scale_factors[R.octave[ir]])
+        for yi in range(int(np.floor(f32(R.y[ir] - r))), int(np.ceil(f32(R.y[ir] + r))) + 1):
+            if 0 <= yi < n_rows:
+                rows[yi].append(ir)
+    idx = np.full(L.n, -1, np.int64); dist = np.full(L.n, 100, np.int64)
+    for il in range(L.n):
+        vl, ul = L.y[il], L.x[il]
+        if not (vl >= 0) or int(vl) >= n_rows:
+            continue
+        cand = rows[int(vl)]                                              # vRowIndices[vL]: float -> index truncates
+        if not cand:
+            continue
+        min_u, max_u = f32(ul - f32(max_d)), f32(ul - f32(0))
+        if max_u < 0:
+            continue
+        bd, bi = 100, -1
+        for ir in cand:
+            if R.octave[ir] < L.octave[il] - 1 or R.octave[ir] > L.octave[il] + 1:
+                continue
+            if min_u <= R.x[ir] <= max_u:
+                d = ham(L.desc[il], R.desc[ir])
+                if d < bd:
+                    bd, bi = d, ir
+        idx[il], dist[il] = bi, bd
+    return idx, dist
+
+
+def test_oracle_stereo_match_against_numpy_restatement(orc):
+    rng = np.random.default_rng(808)
+    n = 300
+    lm = synth.random_descriptors(rng, n)
+    xl = rng.uniform(16, 624, n).astype(np.float32); yl = rng.uniform(16, 464, n).astype(np.float32)
+    octl = synth.octaves_level_major(n)
+    left = synth.make_frame(rng, lm, np.arange(n), x=xl, y=yl, octave=octl, with_fv=False)
+    disp = rng.uniform(-2, 60, n).astype(np.float32)
+    right = synth.make_frame(rng, lm, np.arange(n), x=(xl - disp).astype(np.float32), y=(yl + rng.normal(0, 1.2, n)).astype(np.float32),
+                             octave=np.clip(octl + rng.integers(-2, 3, n), 0, 7).astype(octl.dtype), with_fv=False)
+    left.x[:3] = -1.0
+    left.y[3] = 479.5
+    want_idx, want_dist = _numpy_stereo_match(left, right, 480, 50.0)
+    idx, dist, _ = orc.stereo_match(left, right, 480, 50.0)
+    assert np.array_equal(idx, want_idx) and np.array_equal(dist, want_dist) and (want_idx >= 0).sum() > 100
+
+
+def test_oracle_distinctive_descriptor_against_numpy_restatement(orc):
+    """MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:402-427: per row the sorted distances' element int(0.5 * (N - 1)),
+    the first row with the least such median."""
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 4, 7, 8, 21, 40):
+        base = synth.random_descriptors(rng, 3)
+        d = np.stack([synth.observe(rng, base[rng.integers(0, 3)][None, :], 0.1)[0] for _ in range(n)])
+        D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(axis=2)
+        med = [int(np.sort(D[i])[int(0.5 * (n - 1))]) for i in range(n)]
+        assert orc.distinctive_descriptor(d) == int(np.argmin(med)), n      # argmin: first of the least
+
+
 def test_oracle_bf2nn_against_numpy_restatement(orc):
     """Brute-force 2-NN + TH_LOW + ratio test (SearchByBoW's inner loop over one node holding everything, ORBmatcher.cc:271-312
     without the claims): all distances with numpy, first index wins ties."""
