@@ -620,6 +620,55 @@ def test_oracle_distinctive_descriptor_against_numpy_restatement(orc):
         assert orc.distinctive_descriptor(d) == int(np.argmin(med)), n      # argmin: first of the least
 
 
+def test_oracle_vocabulary_transform_against_numpy_restatement(orc):
+    """TemplatedVocabulary::transform (DBoW2, restated from its published algorithm; not in the reference tree): descent by
+    strict '<' from the first child, node id at level depth - levelsup, features of non-positive weight left out,
+    FeatureVector in feature order, BowVector = weights added in feature order then L1-normalised in word order."""
+    rng = np.random.default_rng(12)
+    voc = synth.make_vocabulary(seed=3, irregular=True, tie_frac=0.1, stop_frac=0.1)
+    feats = synth.vocabulary_features(rng, voc, 300)
+    levelsup = 2
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    words, nodes = [], []
+    for f in feats:
+        nid, level, at_level = 0, 0, 0
+        while voc.child_off[nid + 1] > voc.child_off[nid]:
+            kids = voc.child_idx[voc.child_off[nid]:voc.child_off[nid + 1]]
+            best, bd = int(kids[0]), ham(f, voc.desc[kids[0]])
+            for k in kids[1:]:
+                d = ham(f, voc.desc[k])
+                if d < bd:
+                    best, bd = int(k), d
+            nid = best
+            level += 1
+            if level == voc.depth - levelsup:
+                at_level = nid
+        if voc.depth - levelsup <= 0:
+            at_level = 0
+        words.append(int(voc.word_id[nid]))
+        nodes.append(at_level if voc.weight[nid] > 0 else -1)
+    word, node, (fn, fo, fi), (bw, bv) = orc.transform(voc, feats, levelsup, want_bow=True)
+    assert word.tolist() == words and node.tolist() == nodes
+    fv = {}
+    for i, nd in enumerate(nodes):
+        if nd >= 0:
+            fv.setdefault(nd, []).append(i)
+    keys = sorted(fv)
+    assert fn.tolist() == keys and fi.tolist() == [i for k in keys for i in fv[k]] and fo.tolist() == np.cumsum([0] + [len(fv[k]) for k in keys]).tolist()
+    if voc.weighting in (0, 1) and voc.scoring == 0:                       # TF_IDF / TF, L1: addWeight then normalize
+        bow = {}
+        leaf_of = {int(w): i for i, w in enumerate(voc.word_id) if w >= 0}
+        for i, w in enumerate(words):
+            wt = float(voc.weight[leaf_of[w]])
+            if wt > 0:
+                bow[w] = bow.get(w, 0.0) + wt
+        ws = sorted(bow)
+        norm = 0.0
+        for w in ws:
+            norm += abs(bow[w])
+        assert bw.tolist() == ws and bv.tolist() == [bow[w] / norm for w in ws]
+
+
 def test_oracle_bf2nn_against_numpy_restatement(orc):
     """Brute-force 2-NN + TH_LOW + ratio test (SearchByBoW's inner loop over one node holding everything, ORBmatcher.cc:271-312
     without the claims): all distances with numpy, first index wins ties."""
