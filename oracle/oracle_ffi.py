@@ -216,3 +216,52 @@ def bow_score(a, b):
     common = C.c_int32(0)
     s = lib().orc_bow_score(C.byref(va), C.byref(vb), C.byref(common))
     return float(s), int(common.value)
+
+
+class _CKfDb(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_words", C.c_int32), ("bow", C.POINTER(CBowVecView)), ("mn_id", C.POINTER(C.c_int64)),
+                ("nb_off", C.POINTER(C.c_int32)), ("nb_idx", C.POINTER(C.c_int32)), ("inv_off", C.POINTER(C.c_int32)),
+                ("inv_idx", C.POINTER(C.c_int32)), ("query", C.POINTER(C.c_int64)), ("words", C.POINTER(C.c_int32)),
+                ("score", C.POINTER(C.c_float))]
+
+
+class KfDb:
+    """A keyframe database in flat form for orc_detect_candidates: BowVectors, ids, the best-covisibility lists
+    (GetBestCovisibilityKeyFrames(10), in order) and the inverted file (keyframes per word, in insertion order); query / words /
+    score are the persistent mnLoopQuery|mnRelocQuery, mnLoopWords|mnRelocWords, mLoopScore|mRelocScore fields."""
+
+    def __init__(self, bows, mn_id, neighbours, n_words):
+        self.bows = list(bows)
+        n = len(self.bows)
+        self.mn_id = np.ascontiguousarray(mn_id, np.int64)
+        self.nb_off = np.zeros(n + 1, np.int32)
+        self.nb_off[1:] = np.cumsum([len(x) for x in neighbours])
+        self.nb_idx = np.ascontiguousarray([k for x in neighbours for k in x] or [0], np.int32)
+        inv = [[] for _ in range(n_words)]
+        for k, b in enumerate(self.bows):                     # KeyFrameDatabase::add, KeyFrameDataBase.cc:53-60
+            for w in b.word:
+                inv[int(w)].append(k)
+        self.inv_off = np.zeros(n_words + 1, np.int32)
+        self.inv_off[1:] = np.cumsum([len(x) for x in inv])
+        self.inv_idx = np.ascontiguousarray([k for x in inv for k in x] or [0], np.int32)
+        self.query = np.full(n, -1, np.int64)
+        self.words = np.zeros(n, np.int32)
+        self.score = np.zeros(n, np.float32)
+        self._views = (CBowVecView * max(n, 1))(*[b.view() for b in self.bows])
+        self.n_words = n_words
+
+
+def detect_candidates(is_reloc, db: KfDb, q_bow, q_id, connected=None, min_score=0.0):
+    """KeyFrameDatabase::DetectRelocalizationCandidates / DetectLoopCandidates on a KfDb -> keyframe indices, in order."""
+    L = lib()
+    L.orc_detect_candidates.argtypes = [C.c_int, C.POINTER(_CKfDb), C.POINTER(CBowVecView), C.c_int64, C.POINTER(C.c_uint8), C.c_float,
+                                        C.POINTER(C.c_int32)]
+    n = len(db.bows)
+    c = _CKfDb(n_kf=n, n_words=db.n_words, bow=db._views, mn_id=_p(db.mn_id, C.c_int64), nb_off=_p(db.nb_off, C.c_int32),
+               nb_idx=_p(db.nb_idx, C.c_int32), inv_off=_p(db.inv_off, C.c_int32), inv_idx=_p(db.inv_idx, C.c_int32),
+               query=_p(db.query, C.c_int64), words=_p(db.words, C.c_int32), score=_p(db.score, C.c_float))
+    out = np.zeros(max(n, 1), np.int32)
+    conn = None if connected is None else np.ascontiguousarray(connected, np.uint8)
+    qv = q_bow.view()
+    k = L.orc_detect_candidates(int(is_reloc), C.byref(c), C.byref(qv), int(q_id), _p(conn, C.c_uint8), float(min_score), _p(out, C.c_int32))
+    return out[:k].tolist()

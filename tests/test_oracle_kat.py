@@ -669,6 +669,99 @@ def test_oracle_vocabulary_transform_against_numpy_restatement(orc):
         assert bw.tolist() == ws and bv.tolist() == [bow[w] / norm for w in ws]
 
 
+def _numpy_l1_score(a, b):
+    """DBoW2 L1Scoring::score (restated from the published algorithm): merge walk over ascending word ids, double accumulator."""
+    i = j = 0
+    score = 0.0
+    while i < a.n and j < b.n:
+        if a.word[i] == b.word[j]:
+            vi, wi = float(a.value[i]), float(b.value[j])
+            score += abs(vi - wi) - abs(vi) - abs(wi)
+            i += 1; j += 1
+        elif a.word[i] < b.word[j]:
+            i += 1
+        else:
+            j += 1
+    return -score / 2.0
+
+
+def _numpy_detect_candidates(is_reloc, bows, neighbours, state, q_bow, q_id, connected, min_score):
+    """Slow, independent restatement of KeyFrameDatabase::DetectLoopCandidates (KeyFrameDataBase.cc:109-285) and
+    DetectRelocalizationCandidates (:287-431); state = (query, words, score) persistent per keyframe like mnLoopQuery etc."""
+    f32 = np.float32
+    query, words, score = state
+    inv = {}
+    for k, b in enumerate(bows):
+        for w in b.word:
+            inv.setdefault(int(w), []).append(k)
+    sharing = []
+    for w in q_bow.word:
+        for k in inv.get(int(w), []):
+            if query[k] != q_id:
+                words[k] = 0
+                if is_reloc or not connected[k]:
+                    query[k] = q_id
+                    sharing.append(k)
+            words[k] += 1
+    if not sharing:
+        return []
+    max_common = max(words[k] for k in sharing)
+    min_common = int(f32(max_common) * f32(0.8))
+    scored = []
+    for k in sharing:
+        if words[k] > min_common:
+            si = f32(_numpy_l1_score(q_bow, bows[k]))
+            score[k] = si
+            if is_reloc or si >= f32(min_score):
+                scored.append((si, k))
+    if not scored:
+        return []
+    acc_list = []
+    best_acc = f32(0.0) if is_reloc else f32(min_score)
+    for si, k in scored:
+        best_score, acc, best = si, si, k
+        for k2 in neighbours[k]:
+            if is_reloc:
+                if query[k2] != q_id:
+                    continue
+            elif not (query[k2] == q_id and words[k2] > min_common):
+                continue
+            acc = f32(acc + score[k2])
+            if score[k2] > best_score:
+                best, best_score = k2, score[k2]
+        acc_list.append((acc, best))
+        if acc > best_acc:
+            best_acc = acc
+    retain = f32(f32(0.75) * best_acc)
+    out = []
+    for acc, k in acc_list:
+        if acc > retain and k not in out:
+            out.append(k)
+    return out
+
+
+@pytest.mark.parametrize("is_reloc", [False, True])
+def test_oracle_keyframe_database_against_numpy_restatement(orc, is_reloc):
+    rng = np.random.default_rng(77 + is_reloc)
+    n_words, n = 3000, 48
+    bows = synth.bow_vectors(seed=5, n_vec=n, n_words_vocab=n_words, n_feat=200, shared=0.5, group=6)
+    neighbours = [[int(k2) for k2 in rng.permutation(n)[:rng.integers(0, 11)] if k2 != k] for k in range(n)]
+    db = orc.KfDb(bows, np.arange(n), neighbours, n_words)
+    state = (np.full(n, -1, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float32))
+    total = 0
+    for q in rng.permutation(n)[:24]:                          # queries in sequence: the per-keyframe fields persist between calls
+        connected = np.zeros(n, np.uint8)
+        connected[neighbours[q]] = 1
+        connected[q] = 1
+        min_score = 0.0 if is_reloc else float(rng.choice([0.0, 0.005, 0.02]))
+        want = _numpy_detect_candidates(is_reloc, bows, neighbours, state, bows[q], 1000 + int(q), connected, min_score)
+        got = orc.detect_candidates(is_reloc, db, bows[q], 1000 + int(q), connected, min_score)
+        assert got == want, (int(q), got, want)
+        total += len(want)
+    assert total > 10
+    assert np.array_equal(db.query, state[0]) and np.array_equal(db.words, state[1]) and np.array_equal(db.score, state[2])
+
+
 def test_oracle_bf2nn_against_numpy_restatement(orc):
     """Brute-force 2-NN + TH_LOW + ratio test (SearchByBoW's inner loop over one node holding everything, ORBmatcher.cc:271-312
     without the claims): all distances with numpy, first index wins ties."""
