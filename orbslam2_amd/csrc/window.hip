@@ -195,7 +195,7 @@ constexpr int COST_CLASSES = 64;
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
                                                                   uint32_t *cand, uint32_t *cand_hi, uint8_t *ncand_out,
-                                                                  uint64_t *postable_out, int cap, int stage_nxt) {
+                                                                  uint64_t *postable_out, int cap, int stage_nxt, int groups) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
     const int tid = threadIdx.x;
@@ -223,7 +223,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
     const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
     constexpr int WAVES = COLLECT_THREADS / 64;
-    constexpr int SUPER = 2 * COLLECT_THREADS;      // queries sorted together: two rows of 64 per wave
+    // queries sorted together: `groups` rows of 64 per wave (2; 1 when the launch has few instances, so that one instance
+    // spreads over more workgroups)
+    const int SUPER = groups * COLLECT_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
     // A wave costs what its widest window costs and window areas differ by more than 10x between pyramid levels, so
     // the queries of a super-chunk are counting-sorted by the length of their walk (columns + records) and each
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         int cls[2], rank[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+            if (h >= groups) { cls[h] = 0; rank[h] = 0; continue; }
             const Query t = load_params<MODE>(P, F, S, sc * SUPER + h * COLLECT_THREADS + tid);
             int c = 0;
             if (t.valid) {
@@ -259,12 +262,13 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+            if (h >= groups) continue;
             int start = 0;
             for (int bk = COST_CLASSES - 1; bk > cls[h]; bk--) start += l_bucket[bk];
             l_perm[start + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
         }
         __syncthreads();
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < groups; h++) {
         const int group = h == 0 ? wave : 2 * WAVES - 1 - wave;
         const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
         const int rowi = qi >> 6;
@@ -872,13 +876,16 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
         constexpr int WAVES = COLLECT_THREADS / 64;
         int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
+        // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
+        const int groups = (long long)n_inst * wgs_per_inst < 256 ? 1 : 2;
+        if (groups == 1) wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
         const int stage_nxt = collect_lds_bytes(max_n, true) <= 160 * 1024;
         const size_t lds = collect_lds_bytes(max_n, stage_nxt != 0);
         if (lds > 48 * 1024)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap, stage_nxt);
+                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap, stage_nxt, groups);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
         return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable, cap, cand_hi);
