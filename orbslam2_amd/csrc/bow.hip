@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
 // tuning / test knob: 0 = auto (large batches: queries on lanes, bowq_kernel; small batches, where several workgroups
 // share a pair and a wave gets one or two nodes: candidates on lanes, bow_kernel), 1 = bow_kernel always, 2 = bowq_kernel always
 int g_bow_variant = 0;
+int g_bow_split_below = 2048;   // batches of fewer pairs share each pair between several workgroups
 
 int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, const int32_t *frame_b, float ratio,
                int check_ori, int only_stereo, const float *f12, const float *epipole, int32_t stride,
@@ -700,8 +701,12 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         (rc = io.out(match, out_elems * 4, &dm)) || (rc = io.out(counts, (size_t)n_pairs * 4, &dc)))
         return rc;
     if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
-    // small batches: several workgroups per pair (about 1000 workgroups in all, at most 32 per pair)
-    const int splits = n_pairs >= 512 ? 1 : std::min(32, (1024 + n_pairs - 1) / n_pairs);
+    // One workgroup per pair needs a few thousand pairs to fill the chip (a pair keeps its workgroup 0.1-0.2 ms).  Below that
+    // several workgroups share a pair's nodes, about 4096 workgroups in all and at most 32 per pair; up to 96 pairs the
+    // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
+    // 64 / 256 / 512 / 1024 pairs 0.050 / 0.078 / 0.114 / 0.167 ms against 0.056 / 0.130 / 0.181 / 0.203 ms with one policy for all).
+    const int splits = (n_pairs >= g_bow_split_below || g_bow_variant == 3) ? 1 : std::max(2, std::min(32, (4096 + n_pairs - 1) / n_pairs));
+    const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
     dim3 block(256);
     if (splits == 1) {
         dim3 grid(n_pairs);
@@ -720,7 +725,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         dim3 grid(n_pairs * splits), fgrid(n_pairs);
 #define LAUNCH(M)                                                                                              \
     do {                                                                                                       \
-        hipLaunchKernelGGL((g_bow_variant != 2 ? bow_kernel<M, true> : bowq_kernel<M, true>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+        hipLaunchKernelGGL((split_queries_on_lanes ? bowq_kernel<M, true> : bow_kernel<M, true>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
                            stride, (int32_t *)dm, (int32_t *)dc, splits, acc);                                  \
         hipLaunchKernelGGL((bow_finish_kernel<M>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,   \
@@ -737,6 +742,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
 
 // tuning / test knob (not part of the public ABI): see g_bow_variant
 extern "C" void orbm__bow_variant(int v) { g_bow_variant = v; }
+extern "C" void orbm__bow_split_below(int n_pairs) { g_bow_split_below = n_pairs > 0 ? n_pairs : 2048; }
 
 extern "C" int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
                                      const int32_t *frame_b, float ratio, int check_ori, int32_t stride,

@@ -52,30 +52,44 @@ def test_bow_parity_pool(ctx, orc, variant, check_ori):
 
 @pytest.mark.parametrize("variant", [0, 1])
 def test_bow_large_batch_uses_one_workgroup_per_pair(ctx, orc, variant):
-    """Batches of 512 pairs and more run one workgroup per pair (smaller ones split a pair's nodes over several
-    workgroups): same results either way."""
+    """Large batches run one workgroup per pair, smaller ones split a pair's nodes over several workgroups (the library
+    picks by batch size; the threshold is moved here to take both paths with the same 540 pairs): same results either way."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
     kfs = synth.keyframe_pool(seed=synth.SEED0 + 14, n_kf=6, n=600)
     ids = ctx.upload_frames(kfs)
     pa, pb = np.meshgrid(np.arange(6), np.arange(6))
     pa, pb = np.resize(pa.ravel(), 540), np.resize(pb.ravel(), 540)
-    counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=600)
     want = {}
-    for k, (i, j) in enumerate(zip(pa, pb)):
-        if (i, j) not in want:
-            want[(i, j)] = orc.search_bow(variant, kfs[i], kfs[j], 0.75, True)
-        wc, wm, _ = want[(i, j)]
-        assert counts[k] == wc and np.array_equal(match[k], wm), (k, i, j)
+    try:
+        for split_below in (512, 2048):
+            L.orbm__bow_split_below(split_below)
+            counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=600)
+            for k, (i, j) in enumerate(zip(pa, pb)):
+                if (i, j) not in want:
+                    want[(i, j)] = orc.search_bow(variant, kfs[i], kfs[j], 0.75, True)
+                wc, wm, _ = want[(i, j)]
+                assert counts[k] == wc and np.array_equal(match[k], wm), (split_below, k, i, j)
+    finally:
+        L.orbm__bow_split_below(2048)
     ctx.free_frames(ids)
 
 
 def test_triang_large_batch(ctx, orc):
     c = synth.triang_pair(77, n=800)
     ids = ctx.upload_frames(list(c[:2]))
+    from orbslam2_amd import _lib
+    L = _lib.load()
     P = 520
-    counts, match = ctx.search_triang(np.full(P, ids[0]), np.full(P, ids[1]), np.tile(c[2], (P, 1, 1)), np.tile(c[3], (P, 1)),
-                                      False, True, stride=800)
     wc, wm, _ = orc.search_triang(c[0], c[1], c[2], c[3], False, True)
-    assert (counts == wc).all() and (match == wm[None, :]).all() and wc > 10
+    try:
+        for split_below in (512, 2048):                      # one workgroup per pair / several
+            L.orbm__bow_split_below(split_below)
+            counts, match = ctx.search_triang(np.full(P, ids[0]), np.full(P, ids[1]), np.tile(c[2], (P, 1, 1)), np.tile(c[3], (P, 1)),
+                                              False, True, stride=800)
+            assert (counts == wc).all() and (match == wm[None, :]).all() and wc > 10
+    finally:
+        L.orbm__bow_split_below(2048)
     ctx.free_frames(ids)
 
 
@@ -87,6 +101,7 @@ def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
     L = _lib.load()
     try:
         L.orbm__bow_variant(form)
+        L.orbm__bow_split_below(512)                                      # 81 pairs: split path, 567 / 600: one workgroup per pair
         kfs = synth.keyframe_pool(seed=synth.SEED0 + 24, n_kf=4, n=1200) + contended_pool(31, 3, 700, 150) + \
             contended_pool(41, 2, 300, 10, n_nodes=2)                     # nodes far wider than a wavefront
         ids = ctx.upload_frames(kfs)
@@ -117,6 +132,7 @@ def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
         ctx.free_frames(ids)
     finally:
         L.orbm__bow_variant(0)
+        L.orbm__bow_split_below(2048)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -572,6 +588,7 @@ def test_bow_fuzz_near_thresholds(ctx, orc, form):
     pa = rng.integers(0, len(kfs), 600); pb = rng.integers(0, len(kfs), 600)
     try:
         L.orbm__bow_variant(form)
+        L.orbm__bow_split_below(512)                          # 600 pairs: one workgroup per pair, 40 pairs: split path
         for variant in (0, 1):
             for ratio in (0.75, 0.95):
                 counts, match = ctx.search_bow(variant, ids[pa], ids[pb], ratio, True, stride=400)
@@ -587,6 +604,7 @@ def test_bow_fuzz_near_thresholds(ctx, orc, form):
                     assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (form, variant, ratio, k, "split")
     finally:
         L.orbm__bow_variant(0)
+        L.orbm__bow_split_below(2048)
     ctx.free_frames(ids)
 
 
