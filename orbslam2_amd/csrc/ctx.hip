@@ -178,25 +178,28 @@ __device__ __forceinline__ int pos_in_grid(const FrameG &f, int i) {
 
 constexpr int GRID_LDS_MAX_N = 8192;   // keypoint lists up to this size are ordered in LDS
 
-__global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restrict__ table,
+constexpr int GRID_THREADS = 1024;   // one workgroup per frame: the upload of every per-call search waits for it
+
+__global__ __launch_bounds__(GRID_THREADS) void build_grid_kernel(const FrameDev *__restrict__ table,
                                                          const int32_t *__restrict__ ids) {
     __shared__ __align__(16) uint32_t cnt[ORBM_GRID_CELLS];
     __shared__ uint32_t off[ORBM_GRID_CELLS + 1];
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[GRID_THREADS / 64];
     __shared__ uint16_t lidx[GRID_LDS_MAX_N];
     const FrameG f(table[ids[blockIdx.x]]);
     const int tid = threadIdx.x;
     const int n = f.n;
     const bool in_lds = n <= GRID_LDS_MAX_N;
-    for (int c = tid; c < ORBM_GRID_CELLS; c += 256) cnt[c] = 0;
+    for (int c = tid; c < ORBM_GRID_CELLS; c += GRID_THREADS) cnt[c] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += GRID_THREADS) {
         const int c = pos_in_grid(f, i);
         if (c >= 0) atomicAdd(&cnt[c], 1u);
     }
     __syncthreads();
-    // exclusive scan: 12 consecutive cells per thread, then a wave scan of the 256 partial sums
-    constexpr int PER = ORBM_GRID_CELLS / 256;
+    // exclusive scan: PER consecutive cells per thread, a scan inside each wave, then the waves before this one
+    constexpr int PER = ORBM_GRID_CELLS / GRID_THREADS;
+    static_assert(PER * GRID_THREADS == ORBM_GRID_CELLS, "cells must divide evenly");
     uint32_t loc[PER];
     uint32_t s = 0;
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     __syncthreads();
     uint32_t base = incl - s;
     for (int w = 0; w < (tid >> 6); w++) base += part[w];
-    if (tid == 255) { off[ORBM_GRID_CELLS] = base + s; f.cell_off[ORBM_GRID_CELLS] = base + s; }
+    if (tid == GRID_THREADS - 1) { off[ORBM_GRID_CELLS] = base + s; f.cell_off[ORBM_GRID_CELLS] = base + s; }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const uint32_t o = base + loc[k];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
         cnt[tid * PER + k] = o;  // becomes the scatter cursor
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += GRID_THREADS) {
         const int c = pos_in_grid(f, i);
         if (c < 0) continue;
         const uint32_t at = atomicAdd(&cnt[c], 1u);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     __syncthreads();
     if (!in_lds) __threadfence_block();
     // ascending order inside each cell (lists are short: ~0.65 keypoints per cell at n=2000)
-    for (int c = tid; c < ORBM_GRID_CELLS; c += 256) {
+    for (int c = tid; c < ORBM_GRID_CELLS; c += GRID_THREADS) {
         const uint32_t b = off[c], e = cnt[c];
         if (in_lds) {
             for (uint32_t i = b + 1; i < e; i++) {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     if (!in_lds) __threadfence_block();
     // cell-ordered records, one per list position (independent loads)
     const uint32_t total = off[ORBM_GRID_CELLS];
-    for (uint32_t i = tid; i < total; i += 256) {
+    for (uint32_t i = tid; i < total; i += GRID_THREADS) {
         const uint32_t k = in_lds ? (uint32_t)lidx[i] : f.cell_idx[i];
         if (in_lds) f.cell_idx[i] = k;
         ((gptr<v4f>)f.cell_rec)[i] = v4f{f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16))};
@@ -259,12 +262,12 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
     // skip lists over the cell-ordered stream, one per octave pair {p-1, p}: suffix "first match at or after j".
     // Each thread owns a run of consecutive positions; the carry from the runs to its right is a suffix-min.
     if (f.cell_nxt && in_lds) {
-        uint16_t *firstm = reinterpret_cast<uint16_t *>(cnt);       // [256][8], cnt is free now
+        uint16_t *firstm = reinterpret_cast<uint16_t *>(cnt);       // [waves][8], cnt is free now
         uint8_t *loct = reinterpret_cast<uint8_t *>(off);           // octave per stream position; off is free now (total is in a register)
         __syncthreads();
-        for (uint32_t i = tid; i < total; i += 256) loct[i] = f.octave[lidx[i]];
+        for (uint32_t i = tid; i < total; i += GRID_THREADS) loct[i] = f.octave[lidx[i]];
         __syncthreads();
-        const int per = ((int)total + 256) / 256;                    // positions 0..total-1 (+ the sentinel row `total`)
+        const int per = ((int)total + GRID_THREADS) / GRID_THREADS;                    // positions 0..total-1 (+ the sentinel row `total`)
         const int j0 = tid * per, j1 = min((int)total, j0 + per);
         uint32_t fm[8];
 #pragma unroll
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
 #pragma unroll
             for (int p2 = 0; p2 < 8; p2++) if (o == p2 || o == p2 - 1) fm[p2] = (uint32_t)j;
         }
-        // exclusive suffix-min of fm over the 256 threads (positions grow with tid, so the min is the nearest match)
+        // exclusive suffix-min of fm over the threads (positions grow with tid, so the min is the nearest match)
         uint32_t carry[8];
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void build_grid_kernel(const FrameDev *__restr
         __syncthreads();
 #pragma unroll
         for (int p2 = 0; p2 < 8; p2++) {
-            for (int w = wv + 1; w < 4; w++) carry[p2] = min(carry[p2], (uint32_t)firstm[w * 8 + p2]);
+            for (int w = wv + 1; w < GRID_THREADS / 64; w++) carry[p2] = min(carry[p2], (uint32_t)firstm[w * 8 + p2]);
             if (carry[p2] == 0xFFFFu) carry[p2] = total;
         }
         const gptr<v4u> nxt4 = (gptr<v4u>)f.cell_nxt;
@@ -548,7 +551,7 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         HIPCHK(ctx, hipMemcpyAsync(ctx->ws, out_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     // build the grid-cell CSR on the device
-    hipLaunchKernelGGL(build_grid_kernel, dim3(n_frames), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws);
+    hipLaunchKernelGGL(build_grid_kernel, dim3(n_frames), dim3(GRID_THREADS), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ORBM_OK;
