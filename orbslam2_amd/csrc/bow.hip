@@ -702,11 +702,12 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         return rc;
     if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
     // One workgroup per pair needs a few thousand pairs to fill the chip (a pair keeps its workgroup 0.1-0.2 ms).  Below that
-    // several workgroups share a pair's nodes, about 4096 workgroups in all and at most 32 per pair; up to 96 pairs the
+    // several workgroups share a pair's nodes, about 4096 workgroups in all and at most 32 (16) per pair; up to 96 pairs the
     // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
     // 64 / 256 / 512 / 1024 pairs 0.050 / 0.078 / 0.114 / 0.167 ms against 0.056 / 0.130 / 0.181 / 0.203 ms with one policy for all).
-    const int splits = (n_pairs >= g_bow_split_below || g_bow_variant == 3) ? 1 : std::max(2, std::min(32, (4096 + n_pairs - 1) / n_pairs));
     const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
+    const int splits = (n_pairs >= g_bow_split_below || g_bow_variant == 3) ? 1
+                       : std::max(2, std::min(split_queries_on_lanes ? 16 : 32, (4096 + n_pairs - 1) / n_pairs));
     dim3 block(256);
     if (splits == 1) {
         dim3 grid(n_pairs);

@@ -17,7 +17,7 @@ for n_pairs in [int(x) for x in os.environ.get('SIZES', '64,256,512,1024,2048,40
     cand = ids[1 + rng.choice(len(ids) - 1, min(n_pairs, len(ids) - 1), replace=False)].astype(np.int32)
     cand = np.resize(cand, n_pairs)
     tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(n_pairs, ids[0], np.int32), device=dev)
-    for variant in (1,):
+    for variant in (0, 1):
         for form in (0,):
             L.orbm__bow_variant(form)
             best = 1e30
