@@ -2,7 +2,8 @@
 // MODE bits: 1 = A fragments read from LDS (4 x ds_read_b128 per 8 MFMAs), 2 = the v_max3 fold of both result tiles,
 // 4 = one s_barrier per 32 MFMAs, 8 = staging of the next 128 candidate rows (16 KB) per pass with global_load_lds,
 // 16 = staged from a 64 KB region instead of a 16 MB one, 64 = no vmcnt wait before the barrier, 128 = staging through
-// registers, 256 = one staging load per row tile instead of all at the top, 512 = raw bits + expansion, 1024 = lanes read consecutive chunks, 2048 = scalar base + 32-bit lane offset (see main).
+// registers, 256 = one staging load per row tile instead of all at the top, 512 = raw bits + expansion, 1024 = lanes read consecutive chunks, 2048 = scalar base + 32-bit lane offset,
+// 4096 = a fifth wave per workgroup issues all sixteen staging loads of a pass and multiplies nothing (see main).
 // Build: hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o ubench_mfma4b ubench_mfma4b.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -14,10 +15,10 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int MODE, int LDSV4 = 2048, int NLD = 4>
-__global__ __launch_bounds__(256) void k(int iters, float *sink, unsigned long long *clk, const v4i *__restrict__ store) {
+__global__ __launch_bounds__(320) void k(int iters, float *sink, unsigned long long *clk, const v4i *__restrict__ store) {
     __shared__ v4i tile[LDSV4];                                 // 32 KB like the product kernel
     uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
-    for (int i = threadIdx.x; i < LDSV4; i += 256) {
+    for (int i = threadIdx.x; i < LDSV4; i += blockDim.x) {
         v4i v;
         for (int j = 0; j < 4; j++) { h = h * 1664525u + 1013904223u; v[j] = (int)(0x22222222u | (h & 0x88888888u)); }
         tile[i] = v;
@@ -52,12 +53,24 @@ __global__ __launch_bounds__(256) void k(int iters, float *sink, unsigned long l
             else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                   (__attribute__((address_space(3))) void *)(tile + ((it + 1) & 1) * 1024 + g0), 16, 0, 0);
         };
-        if ((MODE & 8) && !(MODE & 256) && !(MODE & 512)) {
+        if ((MODE & 8) && (MODE & 4096)) {
+            if (wave == 4) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int g0 = __builtin_amdgcn_readfirstlane(j * 64);
+                    const int g = g0 + lane, r = g >> 3, cpos = g & 7;
+                    const v4i *src = src0 + r * 8 + (cpos ^ ((r >> 1) & 7));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tile + ((it + 1) & 1) * 1024 + g0), 16, 0, 0);
+                }
+            }
+        } else if ((MODE & 8) && !(MODE & 256) && !(MODE & 512)) {
 #pragma unroll
             for (int j = 0; j < NLD; j++) stage_part(j & 3);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; rt++) {                        // 4 row tiles = one stage of the product kernel
+            if ((MODE & 4096) && wave == 4) break;
             if ((MODE & 8) && (MODE & 256)) stage_part(rt);        // spread: one part per row tile
             v8i a[4];
 #pragma unroll
@@ -120,17 +133,17 @@ int run(int wgs_per_cu, float *sink, unsigned long long *clk, const v4i *store) 
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     unsigned long long h[2];
     const int iters = 12000, grid = 256 * wgs_per_cu;
-    hipLaunchKernelGGL((k<MODE, LDSV4, NLD>), dim3(grid), dim3(256), 0, 0, 200, sink, clk, store);
+    hipLaunchKernelGGL((k<MODE, LDSV4, NLD>), dim3(grid), dim3((MODE & 4096) ? 320 : 256), 0, 0, 200, sink, clk, store);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<MODE, LDSV4, NLD>), dim3(grid), dim3(256), 0, 0, iters, sink, clk, store);
+    hipLaunchKernelGGL((k<MODE, LDSV4, NLD>), dim3(grid), dim3((MODE & 4096) ? 320 : 256), 0, 0, iters, sink, clk, store);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     CHK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
     const double mfma = (double)grid * 4 * iters * 32;
     const double tflops = mfma * 2.0 * 32 * 32 * 64 / (ms * 1e-3) / 1e12;
     const double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9;
-    printf("%d loads/pass, LDS %d KB, mode %d%s%s%s (%s%s%s), %d waves/SIMD: %.1f ms, %.0f TFLOP/s (%.3f of 10066), clock %.2f GHz, %.1f cycles per MFMA per SIMD\n", NLD, LDSV4 / 64, MODE, (MODE & 64) ? " nowait" : "", (MODE & 128) ? " via-registers" : "", (MODE & 2048) ? " saddr" : (MODE & 1024) ? " linear-global" : (MODE & 512) ? " raw-bits+expand" : (MODE & 256) ? " spread" : "",
+    printf("%d loads/pass, LDS %d KB, mode %d%s%s%s (%s%s%s), %d waves/SIMD: %.1f ms, %.0f TFLOP/s (%.3f of 10066), clock %.2f GHz, %.1f cycles per MFMA per SIMD\n", NLD, LDSV4 / 64, MODE, (MODE & 64) ? " nowait" : "", (MODE & 128) ? " via-registers" : "", (MODE & 4096) ? " loader-wave" : (MODE & 2048) ? " saddr" : (MODE & 1024) ? " linear-global" : (MODE & 512) ? " raw-bits+expand" : (MODE & 256) ? " spread" : "",
            (MODE & 1) ? "lds " : "", (MODE & 2) ? "fold " : "", (MODE & 4) ? ((MODE & 8) ? ((MODE & 16) ? ((MODE & 32) ? "barrier staging-small-half" : "barrier staging-small") : ((MODE & 32) ? "barrier staging-half" : "barrier staging")) : "barrier") : "", wgs_per_cu, ms, tflops, tflops / 10066.3, ghz,
            (double)h[0] / (32.0 * iters * wgs_per_cu));
     return 0;
@@ -141,7 +154,17 @@ int main() {
     CHK(hipMalloc(&sink, 4)); CHK(hipMalloc(&clk, 16));
     v4i *store;
     CHK(hipMalloc(&store, (size_t)16 << 20)); CHK(hipMemset(store, 0x2A, (size_t)16 << 20));
-    const int w = 5;     // workgroups per CU in the grid (the product kernel runs 4 waves per SIMD)
+    {
+        int nb = 0;
+        hipFuncAttributes fa;
+        CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k<15, 2048, 4>, 256, 0));
+        CHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k<15, 2048, 4>)));
+        printf("runtime: %d workgroups of 256 threads per CU for the staging loop (%d VGPRs, %zu B static LDS)\n", nb, fa.numRegs, (size_t)fa.sharedSizeBytes);
+        hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
+        printf("device: %d CUs, %zu B LDS per workgroup max, %zu B per CU, %d regs per block, max threads per CU %d\n", prop.multiProcessorCount,
+               (size_t)prop.sharedMemPerBlock, (size_t)prop.sharedMemPerMultiprocessor, prop.regsPerBlock, prop.maxThreadsPerMultiProcessor);
+    }
+    const int w = 4;     // workgroups per CU in the grid = what is resident with 32 KB of LDS each (scripts/ubench_resid.hip): one round, no tail
     if (run<0, 2048, 0>(w, sink, clk, store) ||            // MFMAs on register operands only (2 accumulator chains per wave)
         run<3, 2048, 0>(w, sink, clk, store) ||            // + A fragments from LDS + the max3 fold
         run<7, 2048, 0>(w, sink, clk, store) ||            // + one barrier per 32 MFMAs
@@ -152,7 +175,9 @@ int main() {
         run<15 + 128, 2048, 4>(w, sink, clk, store) ||     //   through registers + ds_write_b128 instead
         run<7 + 512, 2048, 0>(w, sink, clk, store) ||      //   raw descriptor bits (1 load) expanded to FP4 by the vector ALU
         run<15 + 1024, 2048, 4>(w, sink, clk, store) ||    //   lanes read consecutive 16-byte chunks (no swizzle on the global side)
-        run<15 + 2048, 2048, 4>(w, sink, clk, store))      //   scalar base + 32-bit lane offset addressing
+        run<15 + 2048, 2048, 4>(w, sink, clk, store) ||    //   scalar base + 32-bit lane offset addressing
+        run<15 + 4096, 2048, 0>(w, sink, clk, store) ||    //   a fifth wave does all the staging
+        run<7, 2048, 0>(w, sink, clk, store) || run<15, 2048, 4>(w, sink, clk, store) || run<15 + 4096, 2048, 0>(w, sink, clk, store))
         return 1;
     return 0;
 }
