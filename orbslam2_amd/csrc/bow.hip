@@ -283,7 +283,6 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     __shared__ uint32_t claimed[MAX_N / 32];  // bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint4 s_rows[4][2 * BOWQ_STAGE];   // per wave: the candidate rows of the nodes it is working on
     __shared__ uint32_t s_meta[4][BOWQ_STAGE];    // keypoint index | mp_flags << 16 of each staged candidate
-    __shared__ uint32_t s_pos[4][2];              // per wave: bit per query position still to finalise
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
@@ -302,7 +301,6 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
     __syncthreads();
     uint4 *w_rows = s_rows[wave];
     uint32_t *w_meta = s_meta[wave];
-    uint32_t *w_pos = s_pos[wave];
 
     const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -545,20 +543,16 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
             }
             // ---- finalise in query order inside each node.  A best distance above the threshold can only get worse.
             if ((best >> 16) > thr) qvalid = false;
-            // positions (rank of a query inside its node) that still hold a query: most queries have no plausible match,
-            // so the set is sparse; it is collected in a per-wave LDS word pair and walked bit by bit
-            if (lane < 2) w_pos[lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (qvalid) atomicOr(&w_pos[my_s >> 5], 1u << (my_s & 31));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            unsigned long long positions = (unsigned long long)__builtin_amdgcn_readfirstlane((int)w_pos[0]) |
-                                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w_pos[1]) << 32);
-            while (positions) {
-                const int s2 = __ffsll((long long)positions) - 1;
-                positions &= positions - 1;
-                if (qvalid && my_s == s2) {
+            // Queries still in play are finalised in order inside each node, the nodes of the group side by side: pass r takes
+            // the r-th such query of every node (its rank among the node's lanes that still hold a query), so the group
+            // needs as many passes as its fullest node has such queries, not one per occupied position.
+            const unsigned long long vmask = __ballot(qvalid);
+            const int node_first = lane - my_s;                               // first lane of this lane's node in the group
+            const unsigned long long before = vmask & ((1ull << lane) - 1ull) & ~((1ull << max(node_first, 0)) - 1ull);
+            const int my_rank = __popcll(before);
+            const int npass = wave_max(qvalid ? my_rank + 1 : 0);
+            for (int s2 = 0; s2 < npass; s2++) {
+                if (qvalid && my_rank == s2) {
                     int ib1 = candidate_index(best & 0xFFFFu);
                     bool stale = (claimed[ib1 >> 5] >> (ib1 & 31)) & 1u;
                     if (!stale && second != INITKEY) {
