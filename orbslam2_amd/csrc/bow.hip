@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void bow_kernel(const FrameDev *__restrict__ t
 
     int my_matches = 0;  // wave-uniform, counted on lane 0
     for (int ia = part * 4 + wave; ia < A.n_nodes; ia += 4 * nparts) {
-        const int ib = find_node(B.fv_node, B.n_nodes, A.fv_node[ia]);
+        const uint32_t node_id = A.fv_node[ia];
+        const int guess = min(ia, B.n_nodes - 1);                           // usually the same index on both sides (see bowq_kernel)
+        const int ib = (guess >= 0 && B.fv_node[guess] == node_id) ? guess : find_node(B.fv_node, B.n_nodes, node_id);
         if (ib < 0) continue;
         const uint32_t offA = A.fv_off[ia], nA = A.fv_off[ia + 1] - offA;
         const uint32_t offB = B.fv_off[ib], nB = B.fv_off[ib + 1] - offB;
@@ -324,7 +326,11 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
         const int ia = first + (kb + lane) * nstride;
         uint32_t nA = 0, nB = 0, offA = 0, offB = 0;
         if (ia < A.n_nodes) {
-            const int ib = find_node(B.fv_node, B.n_nodes, A.fv_node[ia]);
+            // two keyframes usually populate the same vocabulary nodes, so the node sits at the same index on both sides:
+            // one probe there before the binary search (seven dependent loads)
+            const uint32_t node_id = A.fv_node[ia];
+            const int guess = min(ia, B.n_nodes - 1);
+            const int ib = (guess >= 0 && B.fv_node[guess] == node_id) ? guess : find_node(B.fv_node, B.n_nodes, node_id);
             if (ib >= 0) {
                 offA = A.fv_off[ia]; nA = A.fv_off[ia + 1] - offA;
                 offB = B.fv_off[ib]; nB = B.fv_off[ib + 1] - offB;
