@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                         const v4u g0 = g[0], g1 = g[1];
                         w_rows[2 * (my_cbase + t)] = make_uint4(g0.x, g0.y, g0.z, g0.w);
                         w_rows[2 * (my_cbase + t) + 1] = make_uint4(g1.x, g1.y, g1.z, g1.w);
-                        w_meta[my_cbase + t] = (uint32_t)idxB | ((uint32_t)B.mp_flags[idxB] << 16);
+                        // the frame side's map-point flags play no part in SearchByBoW(KF, F) (:282 tests the match slot only): no second, dependent load
+                        w_meta[my_cbase + t] = (uint32_t)idxB | (MODE == 0 ? 0u : (uint32_t)B.mp_flags[idxB] << 16);
                     }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                 for (uint32_t t = 0; t < mNB; t++) {
                     int idxB; uint32_t cd[8], fl;
                     if (staged) staged_candidate(t, idxB, cd, fl);
-                    else { idxB = (int)B.fv_idx[mOffB + t]; load_row(B.desc, idxB, cd); fl = B.mp_flags[idxB]; }
+                    else { idxB = (int)B.fv_idx[mOffB + t]; load_row(B.desc, idxB, cd); fl = MODE == 0 ? 0u : B.mp_flags[idxB]; }
                     uint32_t d = 0;
                     if (evaluate(idxB, cd, fl, skip_claimed, d)) update(d, t, best, second);
                 }
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                 int idx_nxt = on ? (int)B.fv_idx[mOffB + min(1u, last)] : 0;
                 uint32_t row_nxt[8];
                 load_row(B.desc, idx_cur, row_nxt);
-                uint32_t fl_nxt = B.mp_flags[idx_cur];
+                uint32_t fl_nxt = MODE == 0 ? 0u : B.mp_flags[idx_cur];
                 for (int t = 0; t < tmax; t++) {
                     uint32_t cd[8];
 #pragma unroll
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void bowq_kernel(const FrameDev *__restrict__ 
                     // issue the loads of the next candidates before touching this one
                     idx_cur = idx_nxt;
                     load_row(B.desc, idx_cur, row_nxt);
-                    fl_nxt = B.mp_flags[idx_cur];
+                    fl_nxt = MODE == 0 ? 0u : B.mp_flags[idx_cur];
                     idx_nxt = on ? (int)B.fv_idx[mOffB + min((uint32_t)t + 2u, last)] : 0;
                     if (on && (uint32_t)t < mNB) {
                         uint32_t d = 0;
