@@ -140,6 +140,21 @@ int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int3
                        std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more
+// dynamic LDS than any launch of that kernel before it on this device (two runtime calls less per windowed search).
+#ifdef __HIPCC__
+#include <atomic>
+template <auto Kernel>
+inline hipError_t orbm_allow_dynamic_lds(const orbm_ctx *ctx, size_t bytes) {
+    static std::atomic<size_t> allowed[64];
+    std::atomic<size_t> &a = allowed[(unsigned)ctx->device & 63u];
+    if (bytes <= 48 * 1024 || bytes <= a.load(std::memory_order_relaxed)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) a.store(bytes, std::memory_order_relaxed);
+    return e;
+}
+#endif
+
 // Helper that stages host index lists / outputs through the I/O workspace when io_on_device == 0.
 struct IoStage {
     orbm_ctx *ctx;

@@ -828,10 +828,7 @@ int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int 
                   const uint32_t *cand_hi = nullptr) {
     const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
                         (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
-    if (lds > 48 * 1024) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&window_kernel<MODE, LDS_FRAME, PRE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    HIPCHK(ctx, (orbm_allow_dynamic_lds<&window_kernel<MODE, LDS_FRAME, PRE>>(ctx, lds)));
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
                        waves_per_inst, cand, ncand, postable, cap, cand_hi);
     HIPCHK(ctx, hipGetLastError());
@@ -881,9 +878,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         if (groups == 1) wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
         const int stage_nxt = collect_lds_bytes(max_n, true) <= 160 * 1024;
         const size_t lds = collect_lds_bytes(max_n, stage_nxt != 0);
-        if (lds > 48 * 1024)
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&collect_kernel<MODE>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
                            waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap, stage_nxt, groups);
         HIPCHK(ctx, hipGetLastError());
