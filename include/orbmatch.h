@@ -246,6 +246,17 @@ int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t
                           const int32_t *frame_b, float ratio, int check_ori, int32_t stride,
                           int32_t *match, int32_t *counts, int io_on_device);
 
+/* ---- allocation-free variant of orbm_search_bow_batch.  NO counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
+ * results as orbm_search_bow_batch(..., io_on_device = 1): frame_a, frame_b, match, counts are DEVICE pointers, the
+ * call only enqueues work on the context's stream, and it calls no hipMalloc / hipFree (the context's workspaces are
+ * not touched).  The per-pair accumulators (rotation histogram + match count) live in a static device array of the
+ * library, 256 KB per GPU, held until the process ends: at most 2048 pairs per call (ORBM_ELIMIT beyond).  Every call
+ * on one GPU shares that array: calls that overlap on one GPU (two contexts / streams) race; calls on one stream do not. */
+int orbm_search_bow_batch_noalloc(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
+                                  const int32_t *frame_b, float ratio, int check_ori, int32_t stride,
+                                  int32_t *match, int32_t *counts);
+
 /* ---- a9: SearchForTriangulation (ORBmatcher.cc:868-1093), batched over pairs ------------------
  * f12: n_pairs x 9 row-major F12; epipole: n_pairs x 2 (ex, ey) of ORBmatcher.cc:883-884 (the
  * 3-D pose arithmetic stays on the host).  match12[p*stride + idx1] = idx2 or -1. */

@@ -17,7 +17,7 @@ SYMBOLS = [
     "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
     "orbm_vocab_upload", "orbm_vocab_free", "orbm_frames_compute_bow", "orbm_vocab_transform", "orbm_frame_fv_download",
     "orbm_bowvecs_upload", "orbm_bowvecs_free", "orbm_bow_score_batch", "orbm_bowvec_download",
-    "orbm_popcount_peak",
+    "orbm_popcount_peak", "orbm_search_bow_batch_noalloc",
 ]
 
 _lib = None
@@ -55,6 +55,7 @@ def load():
     L.orbm_stereo_match_batch.argtypes = [vp, C.c_int, vp, vp, vp, i32, vp, vp, C.c_int]
     L.orbm_bf2nn_batch.argtypes = [vp, C.c_int, vp, vp, f32, C.c_int, i32, vp, vp, vp, vp, C.c_int]
     L.orbm_search_bow_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, f32, C.c_int, i32, vp, vp, C.c_int]
+    L.orbm_search_bow_batch_noalloc.argtypes = [vp, C.c_int, C.c_int, vp, vp, f32, C.c_int, i32, vp, vp]
     L.orbm_search_triang_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, i32, vp, vp, C.c_int]
     L.orbm_search_proj_points_batch.argtypes = [vp, C.c_int, vp, vp, f32, f32, vp, i32, vp, vp, C.c_int]
     L.orbm_search_window_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, i32, vp, vp, C.c_int]

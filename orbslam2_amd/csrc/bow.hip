@@ -12,6 +12,7 @@
 // the erase pass run in the same launch.
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include "orbm_internal.h"
 
 namespace {
@@ -671,9 +672,19 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
 int g_bow_variant = 0;
 int g_bow_split_below = 2048;   // batches of fewer pairs share each pair between several workgroups
 
+// Allocation-free variant (orbm_search_bow_batch_noalloc): the per-pair accumulators of the split path (30 histogram bins +
+// the match count, 32 ints per pair) live in this file-scope device array instead of the context's grow-only workspace.
+// Every GPU the library runs on holds its own copy (256 KB) until the process ends; the host reaches it only through the
+// address hipGetSymbolAddress returns for that device (the array's name is a host-side stand-in, not a device address).
+constexpr int NOALLOC_MAX_PAIRS = 2048;
+static __device__ __align__(256) int scratch[NOALLOC_MAX_PAIRS * 32];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+int *g_scratch_ptr[NOALLOC_MAX_DEVICES];   // per device; written once under g_scratch_mutex, read after orbm_create returned
+std::mutex g_scratch_mutex;
+
 int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, const int32_t *frame_b, float ratio,
                int check_ori, int only_stereo, const float *f12, const float *epipole, int32_t stride,
-               int32_t *match, int32_t *counts, int io_on_device, const char *who) {
+               int32_t *match, int32_t *counts, int io_on_device, const char *who, int *static_acc = nullptr) {
     if (!ctx) return ORBM_EINVAL;
     if (n_pairs < 0 || (n_pairs > 0 && (!frame_a || !frame_b || !match || !counts)) || stride < 0 ||
         (mode == 2 && n_pairs > 0 && (!f12 || !epipole)))
@@ -707,7 +718,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
     // 64 / 256 / 512 / 1024 pairs 0.050 / 0.078 / 0.114 / 0.167 ms against 0.056 / 0.130 / 0.181 / 0.203 ms with one policy for all).
     const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
-    const int splits = (n_pairs >= g_bow_split_below || g_bow_variant == 3) ? 1
+    const int splits = (!static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3)) ? 1
                        : std::max(2, std::min(split_queries_on_lanes ? 16 : 32, (4096 + n_pairs - 1) / n_pairs));
     dim3 block(256);
     if (splits == 1) {
@@ -719,9 +730,11 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
 #undef LAUNCH
     } else {
-        rc = orbm_ws2_reserve(ctx, (size_t)n_pairs * 32 * sizeof(int));
-        if (rc) return rc;
-        int *acc = (int *)ctx->ws2;
+        if (!static_acc) {
+            rc = orbm_ws2_reserve(ctx, (size_t)n_pairs * 32 * sizeof(int));
+            if (rc) return rc;
+        }
+        int *acc = static_acc ? static_acc : (int *)ctx->ws2;
         HIPCHK(ctx, hipMemsetAsync(acc, 0, (size_t)n_pairs * 32 * sizeof(int), ctx->stream));
         if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
         dim3 grid(n_pairs * splits), fgrid(n_pairs);
@@ -742,6 +755,17 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
 
 }  // namespace
 
+// Called by orbm_create with the context's device current: resolves that device's copy of `scratch` once.
+int orbm_bow_scratch_resolve(orbm_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= NOALLOC_MAX_DEVICES) return ORBM_OK;   // such a device simply has no allocation-free entry
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[ctx->device]) return ORBM_OK;
+    int *ptr = nullptr;
+    HIPCHK(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[ctx->device] = ptr;
+    return ORBM_OK;
+}
+
 // tuning / test knob (not part of the public ABI): see g_bow_variant
 extern "C" void orbm__bow_variant(int v) { g_bow_variant = v; }
 extern "C" void orbm__bow_split_below(int n_pairs) { g_bow_split_below = n_pairs > 0 ? n_pairs : 2048; }
@@ -752,6 +776,20 @@ extern "C" int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, co
     if (ctx && variant != 0 && variant != 1) return orbm_fail(ctx, ORBM_EINVAL, "search_bow_batch: variant must be 0 or 1");
     return launch_bow(ctx, variant, n_pairs, frame_a, frame_b, ratio, check_ori, 0, nullptr, nullptr, stride, match,
                       counts, io_on_device, "search_bow_batch");
+}
+
+extern "C" int orbm_search_bow_batch_noalloc(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
+                                             const int32_t *frame_b, float ratio, int check_ori, int32_t stride,
+                                             int32_t *match, int32_t *counts) {
+    if (!ctx) return ORBM_EINVAL;
+    if (variant != 0 && variant != 1) return orbm_fail(ctx, ORBM_EINVAL, "search_bow_batch_noalloc: variant must be 0 or 1");
+    if (n_pairs > NOALLOC_MAX_PAIRS)
+        return orbm_fail(ctx, ORBM_ELIMIT, "search_bow_batch_noalloc: %d pairs exceed the static scratch buffer (%d pairs)", n_pairs,
+                         NOALLOC_MAX_PAIRS);
+    int *acc = ctx->device >= 0 && ctx->device < NOALLOC_MAX_DEVICES ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!acc) return orbm_fail(ctx, ORBM_EHIP, "search_bow_batch_noalloc: no static scratch buffer on device %d", ctx->device);
+    return launch_bow(ctx, variant, n_pairs, frame_a, frame_b, ratio, check_ori, 0, nullptr, nullptr, stride, match, counts,
+                      /*io_on_device=*/1, "search_bow_batch_noalloc", acc);
 }
 
 extern "C" int orbm_search_triang_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,

@@ -372,6 +372,13 @@ orbm_ctx *orbm_create(int device) {
         return nullptr;
     }
     ctx->stream = ctx->own_stream;
+    ctx->err.reserve(512);                     // orbm_fail writes at most 512 bytes: no host allocation on an error path later
+    if (orbm_bow_scratch_resolve(ctx) != ORBM_OK) {
+        g_create_err = ctx->err;
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return nullptr;
+    }
     return ctx;
 }
 

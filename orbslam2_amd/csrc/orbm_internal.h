@@ -139,6 +139,7 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // 
 int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
                        std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
+int orbm_bow_scratch_resolve(orbm_ctx *ctx);         // bow.hip: device address of the static scratch array of ctx->device (orbm_create calls it)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more
 // dynamic LDS than any launch of that kernel before it on this device (two runtime calls less per windowed search).

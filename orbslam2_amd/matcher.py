@@ -262,6 +262,11 @@ class Context:
         self._chk(self._L.orbm_search_bow_batch(self._h, variant, n_pairs, fa_ptr, fb_ptr, ratio, int(check_ori),
                                                 stride, match_ptr, counts_ptr, 1))
 
+    def search_bow_noalloc(self, variant, n_pairs, fa_ptr, fb_ptr, ratio, check_ori, stride, match_ptr, counts_ptr):
+        """Allocation-free variant (device pointers only, at most 2048 pairs; static scratch buffer inside the library)."""
+        self._chk(self._L.orbm_search_bow_batch_noalloc(self._h, variant, n_pairs, fa_ptr, fb_ptr, ratio, int(check_ori),
+                                                        stride, match_ptr, counts_ptr))
+
     # ---- a9 ----
     def search_triang(self, fa, fb, f12, epipole, only_stereo: bool, check_ori: bool, stride: int):
         fa = np.ascontiguousarray(fa, np.int32)
