@@ -227,7 +227,8 @@ int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_
  * For pair p and every row i of frame_a[p]: scan all rows j of frame_b[p] in ascending j with the
  * strict-< best / second-best update of ORBmatcher.cc:290-300, accept iff best <= th and
  * (float)best < ratio*(float)second (ORBmatcher.cc:304-308).
- * match[p*stride+i] = j or -1; best_d / second_d (nullable) get the raw distances (256 = none);
+ * match[p*stride+i] = j or -1 (rows between the a-frame's n and the stride: -1, on both I/O paths); best_d / second_d
+ * (nullable) get the raw distances (256 = none; their rows beyond n are not written);
  * counts[p] = accepted rows.  stride >= max n of the a-frames.
  * The distances are computed on the matrix cores from a +-1 image of each frame (128 B per descriptor, built on the
  * device the first time a frame is used here and released with the frame); results are identical to the xor + popcount
@@ -235,6 +236,45 @@ int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_
 int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                      float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
                      int32_t *second_d, int32_t *counts, int io_on_device);
+/* Builds the +-1 images of every live frame NOW (one launch + one stream synchronisation).  Without it the first
+ * orbm_bf2nn_batch call that meets a frame builds its image and synchronises; with io_on_device = 1 that first call builds
+ * the images of ALL live frames.  After it, device-path calls only enqueue work (until new frames are uploaded). */
+int orbm_bf2nn_prepare(orbm_ctx *ctx);
+
+/* ---- BASELINE config 5 / SURVEY 8(e): batched keyframe-pair matching that leaves COMPACT match records ----------------
+ * The loops this replaces: LoopClosing.cc:433-477 (SearchByBoW against every consistent candidate, a pair is kept only
+ * if nmatches >= 20, :459) and Tracking.cc:1778-1801 (relocalisation candidates, >= 15, :1787); all-pairs matching is
+ * the same loop over the whole pair triangle.  Record format (what travels to the host or to rank 0):
+ *   summaries[p] = { pair_id[p] (or p when pair_id is NULL), nmatches, 0 }          8 bytes for EVERY pair
+ *   lists        = (u16 row | u16 value << 16) x nmatches, ascending row, ONLY for pairs with nmatches >= threshold
+ *                  (and > 0), pair after pair in batch order: a pair's list starts at the running sum of the accepted
+ *                  pairs' nmatches before it.  row / value = index / content of the pair's match row (idx1 -> idx2 for
+ *                  the brute-force search and SearchByBoW(KF,KF); idxF -> idxKF for SearchByBoW(KF,F)).
+ *   totals[0] = number of accepted pairs, totals[1] = list entries of the batch.  If totals[1] > list_cap the lists
+ *   were cut at list_cap entries (the summaries are complete): call again with a larger buffer. */
+#define ORBM_PAIR_PAD 0xFFFFFFFFu   /* pair_id of a padding entry (fixed-size batches): reported with n = 0 and never listed */
+typedef struct orbm_pair_summary {
+    uint32_t pair_id;
+    uint16_t n;      /* nmatches of the pair */
+    uint16_t pad;    /* 0 */
+} orbm_pair_summary;
+/* Compacts match rows + counts as the searches above return them (entries of a row beyond its frame's n must be -1). */
+int orbm_pack_records(orbm_ctx *ctx, int n_pairs, const uint32_t *pair_id, const int32_t *counts, const int32_t *match,
+                      int32_t stride, int threshold, orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap,
+                      uint32_t *totals, int io_on_device);
+/* Match + compact in one call; the match rows stay in a workspace of the context.  kind 0 = brute-force 2-NN
+ * (ratio, th as orbm_bf2nn_batch), 1 = SearchByBoW(KF,KF), 2 = SearchByBoW(KF,F) (ratio, check_ori as orbm_search_bow_batch).
+ * stride >= the rows a pair needs (n of the a-frame; of the b-frame for kind 2), at most 65536. */
+int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
+                        const uint32_t *pair_id, float ratio, int th, int check_ori, int32_t stride, int threshold,
+                        orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap, uint32_t *totals, int io_on_device);
+/* Block-cyclic sharding of the pair triangle {(a, b): 0 <= a < b < n_kf} over `world` GPUs (host arithmetic, no context):
+ * the triangle is cut into tile x tile blocks of keyframes (row-major over the upper-triangular blocks), block k belongs to
+ * rank k % world, pairs inside a block ascend in a, then b: a block's pairs touch 2 x tile keyframes, whose descriptors sit
+ * in one L2.  Returns the number of pairs of the rank's shard; with pair_a / pair_b non-NULL fills entries
+ * [first, first + max_pairs) of the shard's enumeration.  No data-path collective: every GPU holds the whole store. */
+int64_t orbm_allpairs_shard(int n_kf, int tile, int rank, int world, int64_t first, int64_t max_pairs, int32_t *pair_a,
+                            int32_t *pair_b);
 
 /* ---- a7 / a8: SearchByBoW (ORBmatcher.cc:218-385 and 703-854), batched over pairs -------------
  * variant 0 = (KeyFrame*, Frame&): a = KF, b = F; match[p*stride + idxF] = idxKF whose map point

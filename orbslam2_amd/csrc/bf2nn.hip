@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
     const int nA = A.n, nB = B.n;
     const int tid = threadIdx.x;
     const int q0 = qb * (256 * R) + tid;
-    if (qb * (256 * R) >= nA) return;  // whole block idle (uniform)
+    if (qb * (256 * R) >= nA) {        // whole block idle (uniform): its rows read "no match" up to the stride
+        for (int r = 0; r < R; r++) if (q0 + r * 256 < stride) match[(size_t)p * stride + q0 + r * 256] = -1;
+        return;
+    }
 
     uint32_t q[R][8];
     uint32_t best[R], second[R], bias[R];
@@ -193,6 +196,8 @@ __global__ __launch_bounds__(256) void bf2nn_kernel(const FrameDev *__restrict__
             match[o] = m;
             if (best_d) best_d[o] = bd;
             if (second_d) second_d[o] = sd;
+        } else if (qi < stride) {
+            match[(size_t)p * stride + qi] = -1;        // rows between the frame's n and the stride: no match
         }
     }
     // one atomic per wave
@@ -229,7 +234,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
     const int qb = bid - p * blocks_per_pair;
     const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nA = A.n, nB = B.n;
-    if (qb * 256 >= nA) return;        // whole block idle (uniform)
+    if (qb * 256 >= nA) {              // whole block idle (uniform): its rows read "no match" up to the stride
+        if (qb * 256 + (int)threadIdx.x < stride) match[(size_t)p * stride + qb * 256 + threadIdx.x] = -1;
+        return;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
     const int nA8 = max(32, (nA + 31) & ~31), nB8 = (nB + 31) & ~31;
     const int qbase = qb * 256 + wave * 64;
@@ -321,6 +329,8 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
                 if (best_d) best_d[o] = bd;
                 if (second_d) second_d[o] = sd;
             }
+        } else if (h == 0 && qi < stride) {
+            match[(size_t)p * stride + qi] = -1;        // rows between the frame's n and the stride: no match
         }
     }
     for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
@@ -355,7 +365,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int nA = A.n, nB = B.n;
     constexpr int QW = 32 * NT;        // queries per wave: NT tiles of 32
-    if (qb * (4 * QW) >= nA) return;   // whole block idle (uniform)
+    if (qb * (4 * QW) >= nA) {         // whole block idle (uniform): its rows read "no match" up to the stride
+        for (int i = threadIdx.x; i < 4 * QW; i += 256) if (qb * (4 * QW) + i < stride) match[(size_t)p * stride + qb * (4 * QW) + i] = -1;
+        return;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
     const int nA8 = max(32, (nA + 31) & ~31), nB8 = (nB + 31) & ~31;
     const int qbase = qb * (4 * QW) + wave * QW;
@@ -467,6 +480,8 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
                 if (best_d) best_d[o] = bd;
                 if (second_d) second_d[o] = sd;
             }
+        } else if (h == 0 && qi < stride) {
+            match[(size_t)p * stride + qi] = -1;        // rows between the frame's n and the stride: no match
         }
     }
     for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
@@ -479,6 +494,23 @@ int g_bf_variant = 0;
 
 // tuning / diagnostic knob used by scripts/ (not part of the public ABI)
 extern "C" void orbm__bf2nn_variant(int v) { g_bf_variant = v; }
+
+// 0 = default: the MX-scaled FP4 MFMA form (10); 11 = the vector-ALU kernel; the rest are A/B and diagnostic forms
+static int bf2nn_variant_in_use() {
+    // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
+    static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
+    // ORBMATCH_BF2NN_KERNEL=valu selects the vector-ALU xor + popcount kernel (no +-1 image of the frames is built)
+    static const bool env_valu = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return e && !strcmp(e, "valu"); }();
+    return g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : 10;
+}
+
+extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx) {
+    if (!ctx) return ORBM_EINVAL;
+    const int variant = bf2nn_variant_in_use();
+    if (variant != 9 && variant != 10) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return orbm_ensure_image(ctx, variant == 9 ? 8 : 4, 0, nullptr);
+}
 
 extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                                 float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
@@ -505,12 +537,7 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         else HIPCHK(ctx, hipMemsetAsync(counts, 0, (size_t)n_pairs * 4, ctx->stream));
         return ORBM_OK;
     }
-    // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
-    static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
-    // ORBMATCH_BF2NN_KERNEL=valu selects the vector-ALU xor + popcount kernel (no +-1 image of the frames is built)
-    static const bool env_valu = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return e && !strcmp(e, "valu"); }();
-    // 0 = default: the MX-scaled FP4 MFMA form (10); 11 = the vector-ALU kernel; the rest are A/B and diagnostic forms
-    const int variant = g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : 10;
+    const int variant = bf2nn_variant_in_use();
     if (variant == 9 || variant == 10) {    // MFMA forms: +-1 images of the frames, built on first use (before any staging: it uses the workspace)
         const int bits = variant == 9 ? 8 : 4;
         int rc8 = orbm_ensure_image(ctx, bits, io_on_device ? 0 : n_pairs, io_on_device ? nullptr : frame_a);

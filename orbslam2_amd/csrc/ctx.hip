@@ -397,6 +397,7 @@ void orbm_destroy(orbm_ctx *ctx) {
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_up) (void)hipHostFree(ctx->pin_up);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->ws3) (void)hipFree(ctx->ws3);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

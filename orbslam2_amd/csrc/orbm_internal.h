@@ -118,6 +118,8 @@ struct orbm_ctx {
     size_t pin_up_bytes = 0;
     void *ws2 = nullptr;   // kernel scratch (separate from I/O staging)
     size_t ws2_bytes = 0;
+    void *ws3 = nullptr;   // orbm_allpairs_batch: match rows + counts of the batch (they never leave the device)
+    size_t ws3_bytes = 0;
 };
 
 int orbm_fail(orbm_ctx *ctx, int code, const char *fmt, ...);
@@ -139,6 +141,7 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // 
 int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
                        std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
+extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx);
 int orbm_bow_scratch_resolve(orbm_ctx *ctx);         // bow.hip: device address of the static scratch array of ctx->device (orbm_create calls it)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more

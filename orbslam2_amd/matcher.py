@@ -247,6 +247,37 @@ class Context:
         self._chk(self._L.orbm_bf2nn_batch(self._h, n_pairs, fa_ptr, fb_ptr, ratio, th, stride, match_ptr, best_ptr,
                                            second_ptr, counts_ptr, 1))
 
+    def bf2nn_prepare(self):
+        """Builds the +-1 images of every live frame now, so that later device-path bf2nn calls only enqueue work."""
+        self._chk(self._L.orbm_bf2nn_prepare(self._h))
+
+    # ---- config 5: match + compact records (SURVEY 8(e)) ----
+    SUMMARY_DTYPE = np.dtype([("pair_id", np.uint32), ("n", np.uint16), ("pad", np.uint16)])
+
+    def pack_records(self, pair_id, counts, match, threshold: int, list_cap: int):
+        counts = np.ascontiguousarray(counts, np.int32); match = np.ascontiguousarray(match, np.int32)
+        p, stride = match.shape
+        pid = None if pair_id is None else np.ascontiguousarray(pair_id, np.uint32)
+        summ = np.zeros(max(p, 1), self.SUMMARY_DTYPE); lists = np.zeros(max(list_cap, 1), np.uint32); totals = np.zeros(2, np.uint32)
+        self._chk(self._L.orbm_pack_records(self._h, p, _addr(pid), _addr(counts), _addr(match), stride, threshold, _addr(summ),
+                                            _addr(lists) if list_cap else None, list_cap, _addr(totals), 0))
+        return summ[:p], lists[: min(int(totals[1]), list_cap)], totals
+
+    def allpairs_batch(self, kind: int, fa, fb, pair_id, ratio: float, th: int, check_ori: bool, stride: int, threshold: int,
+                       list_cap: int):
+        fa = np.ascontiguousarray(fa, np.int32); fb = np.ascontiguousarray(fb, np.int32)
+        p = len(fa)
+        pid = None if pair_id is None else np.ascontiguousarray(pair_id, np.uint32)
+        summ = np.zeros(max(p, 1), self.SUMMARY_DTYPE); lists = np.zeros(max(list_cap, 1), np.uint32); totals = np.zeros(2, np.uint32)
+        self._chk(self._L.orbm_allpairs_batch(self._h, kind, p, _addr(fa), _addr(fb), _addr(pid), ratio, th, int(check_ori), stride,
+                                              threshold, _addr(summ), _addr(lists) if list_cap else None, list_cap, _addr(totals), 0))
+        return summ[:p], lists[: min(int(totals[1]), list_cap)], totals
+
+    def allpairs_batch_dev(self, kind, n_pairs, fa_ptr, fb_ptr, pair_id_ptr, ratio, th, check_ori, stride, threshold,
+                           summaries_ptr, lists_ptr, list_cap, totals_ptr):
+        self._chk(self._L.orbm_allpairs_batch(self._h, kind, n_pairs, fa_ptr, fb_ptr, pair_id_ptr, ratio, th, int(check_ori), stride,
+                                              threshold, summaries_ptr, lists_ptr, list_cap, totals_ptr, 1))
+
     # ---- a7 / a8 ----
     def search_bow(self, variant: int, fa, fb, ratio: float, check_ori: bool, stride: int):
         fa = np.ascontiguousarray(fa, np.int32)

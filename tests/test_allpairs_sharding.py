@@ -1,5 +1,5 @@
-"""CPU tests (no GPU): pair sharding and the gather of match records with world_size 2 on gloo, and the C ABI
-library loading with every symbol include/orbmatch.h declares."""
+"""CPU tests (no GPU): pair sharding (the C entry point orbm_allpairs_shard), the exchange of compact match records with
+world_size 2 on gloo, and the C ABI library loading with every symbol include/orbmatch.h declares."""
 import os
 import re
 import sys
@@ -13,15 +13,33 @@ import torch.multiprocessing as mp
 from orbslam2_amd import allpairs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("n_kf,world,tile", [(1, 1, 32), (2, 2, 32), (97, 1, 16), (97, 2, 16), (97, 8, 16), (450, 8, 32), (31, 4, 64)])
+def _tiles_by_hand(n_kf, rank, world, tile):
+    """The sharding rule restated in plain Python: upper-triangular tiles row-major, tile k to rank k % world."""
+    nt = (n_kf + tile - 1) // tile
+    out, k = [], 0
+    for ti in range(nt):
+        for tj in range(ti, nt):
+            if k % world == rank:
+                for a in range(ti * tile, min(n_kf, (ti + 1) * tile)):
+                    for b in range(tj * tile, min(n_kf, (tj + 1) * tile)):
+                        if a < b:
+                            out.append((a, b))
+            k += 1
+    return out
+
+
+@pytest.mark.parametrize("n_kf,world,tile", [(0, 1, 32), (1, 1, 32), (2, 2, 32), (97, 1, 16), (97, 2, 16), (97, 8, 16), (450, 8, 32), (31, 4, 64)])
 def test_shards_partition_all_pairs(n_kf, world, tile):
     seen = set()
     sizes = []
     for r in range(world):
         a, b = allpairs.shard_pairs(n_kf, r, world, tile)
         assert (a < b).all()
+        assert list(zip(a.tolist(), b.tolist())) == _tiles_by_hand(n_kf, r, world, tile)
+        assert allpairs.shard_size(n_kf, r, world, tile) == len(a)
         pairs = set(zip(a.tolist(), b.tolist()))
         assert len(pairs) == len(a)
         assert not (pairs & seen)
@@ -32,44 +50,100 @@ def test_shards_partition_all_pairs(n_kf, world, tile):
         assert max(sizes) <= 1.15 * (sum(sizes) / world)      # balanced despite the triangle
 
 
-def _fake_match(stride):
-    def fn(ta, tb):
-        counts = ((ta * 7 + tb * 13) % 50).to(torch.int32)
-        match = (ta[:, None] * 1000 + tb[:, None] + torch.arange(stride, dtype=torch.int32)[None, :]).to(torch.int32)
-        return counts, match
+def test_shard_windows_agree_with_the_whole_enumeration():
+    a, b = allpairs.shard_pairs(211, 1, 3, 16)
+    for first, count in ((0, 1), (5, 100), (len(a) - 7, 50), (len(a), 10), (1000, 4097)):
+        wa, wb = allpairs.shard_pairs(211, 1, 3, 16, first=first, count=count)
+        assert np.array_equal(wa, a[first:first + count]) and np.array_equal(wb, b[first:first + count])
+    assert allpairs.shard_size(4500, 0, 1, 32) == 4500 * 4499 // 2
+    with pytest.raises(ValueError):
+        allpairs.shard_size(10, 3, 2, 32)
+
+
+STRIDE = 40
+
+
+def _fake_rows(a, b, pid):
+    """A stand-in matcher: deterministic counts (about one pair in five reaches 20) and match rows with exactly that many entries."""
+    p = len(a)
+    counts = ((a.astype(np.int64) * 7 + b * 13) % 25).astype(np.int32)
+    match = np.full((p, STRIDE), -1, np.int32)
+    for k in range(p):
+        rows = (np.arange(counts[k]) * 3 + a[k]) % STRIDE
+        rows = np.unique(rows)[: counts[k]]
+        counts[k] = len(rows)
+        match[k, rows] = (rows * 5 + b[k]) % 60000
+    return counts, match
+
+
+def _fake_batch_fn(threshold):
+    import packref
+
+    def fn(a, b, pid):
+        counts, match = _fake_rows(a, b, pid)
+        summ, lists, (acc, ent) = packref.pack(pid, counts, match, threshold)
+        t = torch.empty(len(a) + 1, dtype=torch.int64)
+        t[: len(a)] = torch.from_numpy(summ.view(np.int64).copy())
+        t[len(a)] = (ent << 32) | acc
+        return t, torch.from_numpy(lists.view(np.int32).copy()), ent
     return fn
+
+
+def _check(res, n_kf, threshold):
+    assert len(res) == n_kf * (n_kf - 1) // 2
+    counts = res.counts()
+    n_acc = 0
+    listed = {pair: (i1, i2) for pair, i1, i2 in res.accepted()}
+    for a in range(n_kf):
+        for b in range(a + 1, n_kf):
+            c, m = _fake_rows(np.array([a]), np.array([b]), None)
+            assert counts[(a, b)] == c[0]
+            if c[0] >= threshold and c[0] > 0:
+                n_acc += 1
+                i1, i2 = listed[(a, b)]
+                rows = np.nonzero(m[0] >= 0)[0]
+                assert np.array_equal(i1, rows) and np.array_equal(i2, m[0][rows])
+                assert np.array_equal(res.match_row(a, b, STRIDE), m[0])
+            else:
+                assert (a, b) not in listed and res.match_row(a, b, STRIDE) is None
+    assert n_acc == len(listed) and n_acc > 10
 
 
 def _worker(rank, world, port, n_kf, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = allpairs.all_pairs(torch, dist, n_kf, stride=5, batch=64, match_fn=_fake_match(5), rank=rank, world=world, tile=8)
+    res = allpairs.all_pairs(torch, dist, n_kf, batch=64, threshold=20, batch_fn=_fake_batch_fn(20), rank=rank, world=world, tile=8)
     if rank == 0:
-        q.put({k: (v[0], v[1].tolist()) for k, v in res.items()})
+        try:
+            _check(res, n_kf, 20)
+            # bytes over the wire: 8 per pair (+ header) + 4 per listed match, only the other rank's share
+            other = allpairs.shard_size(n_kf, 1, world, 8)
+            q.put(("ok", res.bytes_received, other))
+        except Exception as e:  # noqa: BLE001
+            q.put(("fail", repr(e), 0))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_world2_gloo():
+def test_exchange_world2_gloo():
     n_kf, world = 45, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_kf, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = q.get(timeout=120)
+    status, got, other = q.get(timeout=120)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert len(res) == n_kf * (n_kf - 1) // 2
-    for (a, b), (cnt, row) in res.items():
-        assert cnt == (a * 7 + b * 13) % 50
-        assert row == [a * 1000 + b + k for k in range(5)]
+    assert status == "ok", got
+    assert got >= other * 8 and got < other * 8 + 4 * other * 25 + 16 * 64 * 10
 
 
 def test_single_rank_needs_no_process_group():
-    res = allpairs.all_pairs(torch, None, 20, stride=3, batch=16, match_fn=_fake_match(3))
-    assert len(res) == 190 and res[(3, 7)][0] == (3 * 7 + 7 * 13) % 50
+    res = allpairs.all_pairs(torch, None, 20, batch=16, threshold=20, batch_fn=_fake_batch_fn(20))
+    _check(res, 20, 20)
+    assert res.bytes_received == 0
 
 
 def test_c_abi_exports_every_declared_symbol():

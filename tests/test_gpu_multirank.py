@@ -1,6 +1,7 @@
 """Two ranks (gloo, both on the one GPU of the test box): every rank runs the real kernels on its shard of the pair
-triangle, the match records are gathered on rank 0 and compared with the oracle pair by pair.  The N-GPU path of
-bench.py / allpairs.py differs only in the backend (RCCL) and in each rank owning its own GPU."""
+triangle (orbm_allpairs_batch: match + compact records on the device), the records are exchanged as allpairs.py
+describes (fixed-size summaries + variable-length lists) and rank 0 compares every pair with the oracle.  The N-GPU path of
+bench.py differs only in the backend (RCCL) and in each rank owning its own GPU."""
 import os
 
 import numpy as np
@@ -11,7 +12,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-N_KF, N_FEAT = 20, 500
+N_KF, N_FEAT, THRESHOLD = 20, 500, 20
 
 
 def _pool():
@@ -29,22 +30,13 @@ def _worker(rank, world, port, kind, q):
     ctx = Context(0)
     ids = torch.tensor(ctx.upload_frames(_pool()).astype(np.int32), device="cuda:0")
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def match_fn(ta, tb):           # pair lists arrive on the host (gloo), the kernels run on device-resident lists
-        fa = ids[ta.long().cuda()].contiguous(); fb = ids[tb.long().cuda()].contiguous()
-        p = fa.numel()
-        match = torch.empty((p, N_FEAT), dtype=torch.int32, device="cuda:0")
-        counts = torch.empty(p, dtype=torch.int32, device="cuda:0")
-        if kind == "bf":
-            ctx.bf2nn_dev(p, fa.data_ptr(), fb.data_ptr(), 0.75, 50, N_FEAT, match.data_ptr(), None, None, counts.data_ptr())
-        else:
-            ctx.search_bow_dev(1, p, fa.data_ptr(), fb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
-        torch.cuda.synchronize()
-        return counts.cpu(), match.cpu()
-
-    res = allpairs.all_pairs(torch, dist, N_KF, stride=N_FEAT, batch=48, match_fn=match_fn, rank=rank, world=world, tile=4)
+    fn = allpairs.device_batch_fn(torch, ctx, ids, 0 if kind == "bf" else 1, 0.75, 50, True, N_FEAT, THRESHOLD,
+                                  list_cap=48 * N_FEAT, comm_device="cpu")
+    res = allpairs.all_pairs(torch, dist, N_KF, batch=48, threshold=THRESHOLD, batch_fn=fn, rank=rank, world=world, tile=4,
+                             comm_device="cpu", list_cap=48 * N_FEAT)
     if rank == 0:
-        q.put({k: (v[0], v[1].tolist()) for k, v in res.items()})
+        q.put((res.counts(), [(p, i1.tolist(), i2.tolist()) for p, i1, i2 in res.accepted()], res.bytes_received,
+               allpairs.shard_size(N_KF, 1, world, 4)))
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -59,7 +51,7 @@ def test_two_ranks_match_their_shards_and_rank0_gets_every_pair(orc, kind):
     procs = [mpc.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
     [p.start() for p in procs]
     try:
-        res = q.get(timeout=240)
+        counts, accepted, bytes_received, n_remote = q.get(timeout=240)
     finally:
         [p.join(60) for p in procs]
         for p in procs:
@@ -67,13 +59,22 @@ def test_two_ranks_match_their_shards_and_rank0_gets_every_pair(orc, kind):
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
     kfs = _pool()
-    assert len(res) == N_KF * (N_KF - 1) // 2
-    total = 0
-    for (a, b), (cnt, row) in res.items():
+    assert len(counts) == N_KF * (N_KF - 1) // 2
+    listed = {p: (i1, i2) for p, i1, i2 in accepted}
+    total = n_listed = 0
+    for (a, b), cnt in counts.items():
         if kind == "bf":
             wc, wm, _, _, _ = orc.bf2nn(kfs[a], kfs[b], 0.75, 50)
         else:
             wc, wm, _ = orc.search_bow(1, kfs[a], kfs[b], 0.75, True)
-        assert cnt == wc and row[:kfs[a].n] == wm.tolist(), (a, b)
+        assert cnt == wc, (a, b)
+        if wc >= THRESHOLD:
+            rows = np.nonzero(wm >= 0)[0]
+            assert listed[(a, b)] == (rows.tolist(), wm[rows].tolist()), (a, b)
+            n_listed += 1
+        else:
+            assert (a, b) not in listed
         total += cnt
-    assert total > 500
+    assert total > 500 and n_listed == len(listed) and n_listed > 5
+    # what crossed between the ranks: 8 bytes per pair (+ header and last-batch padding) + 4 bytes per listed match
+    assert bytes_received <= (n_remote + 48) * 8 + 8 * 8 + 4 * total
