@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the ORB-SLAM2 matcher hot path on MI355X.
 
-Workload (BASELINE.json configs[1], batched so that one launch fills the chip): brute-force 2-NN
-Hamming + TH_LOW threshold + ratio test between keyframe pairs of 2000 x 2000 256-bit descriptors.
-One "step" = one launch over PAIRS keyframe pairs drawn from a device-resident store of synthetic
-keyframes (50 % shared landmarks between neighbours, bit-flip noise 0.08).  With N GPUs every rank
-matches its own PAIRS pairs of the replicated store (weak scaling, no data-path collective) and the
-match lists are gathered to rank 0 with RCCL (torch.distributed "nccl"), overlapped with the next step.
+Workload: BASELINE.json configs[1] (brute-force 2-NN Hamming + TH_LOW threshold + ratio test, 2000 x 2000 256-bit
+descriptors per keyframe pair), batched the way configs[4] asks for it: the pairs are the upper triangle of a
+device-resident store of 4500 synthetic keyframes x 2000 features (sliding-window landmark visibility: neighbours overlap
+~60 %, far keyframes ~0 %), cut into 32 x 32 keyframe tiles that are dealt block-cyclically to the ranks
+(orbm_allpairs_shard).  Every rank holds the whole store (no data-path collective) and walks ITS shard:
 
-Prints ONE JSON line (contract in the task statement).  `value` = G Hamming comparisons / s over all
-ranks with inputs resident in HBM; keyframe-pairs / s and the secondary paths are in `extra`.
+  one launch = orbm_allpairs_batch over PAIRS consecutive pairs of the shard: the matching kernel, then the compaction of
+               the match rows into 8-byte per-pair summaries + (u16,u16) lists for pairs with >= 20 matches
+               (LoopClosing.cc:459); match rows never leave the GPU;
+  one step   = LAUNCHES such launches (so that --steps 20 times about half a second, not 30 ms);
+  N > 1      = the records of launch k travel to rank 0 over RCCL (torch.distributed "nccl": one fixed-size gather of the
+               summaries, then the variable-length lists point to point) on a second stream while launch k + 1 is matched.
+
+Weak scaling: every rank does PAIRS x LAUNCHES pairs per step whatever N is; a rank whose shard is shorter than the run
+wraps around to its beginning (the records still travel).  Prints ONE JSON line (contract in the task statement): `value` =
+G Hamming comparisons / s over all ranks with inputs resident in HBM; keyframe pairs / s and the secondary paths in `extra`.
 """
 import argparse
 import json
@@ -24,95 +31,151 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_FEAT = 2000
-STORE_KF = 96
-PAIRS_PER_STEP = 4096
+STORE_KF = 4500
+TILE = 32
+PAIRS_PER_LAUNCH = 16384
+LAUNCHES_PER_STEP = 5
+LIST_CAP = 1 << 21          # list entries per launch (8 MB); a diagonal-heavy launch of the store holds ~2 x 10^5
+ACCEPT = 20                 # LoopClosing.cc:459
 RATIO, TH = 0.75, 50
+SMALL_KF = 96               # keyframes of the store that the secondary measurements and the CPU baseline use
 # The headline kernel computes Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA,
 # DESIGN.md section 4.1): one comparison = a 256-long dot product = 512 FLOP.  Dense FP4 peak: one
 # v_mfma_scale_f32_32x32x64_f8f6f4 (2 * 32 * 32 * 64 FLOP) per 32 cycles per SIMD, 256 CUs x 4 SIMDs @ 2.4 GHz
 FLOP_PER_CMP = 512.0
 PEAK_MFMA_TFLOPS = 256 * 4 * (2 * 32 * 32 * 64 / 32.0) * 2.4e9 / 1e12
-# integer-popcount roofline of the vector-ALU kernel (reported in `extra`): per wave64 comparison one SIMD must issue
+# integer-popcount roofline of the vector-ALU kernel (reported beside it): per wave64 comparison one SIMD must issue
 # 8 v_xor_b32 (2 cycles each) + 8 v_bcnt_u32_b32 (4 cycles each) = 48 cycles; 256 CUs x 4 SIMDs x 64 lanes @ 2.4 GHz
 PEAK_TCMPS = 256 * 4 * 64 * 2.4e9 / 48.0 / 1e12
 
 
-def build_store(ctx, seed):
+def build_store(ctx, n_kf, keep_host=SMALL_KF):
+    """The config-5 store, generated and uploaded 250 keyframes at a time (same on every rank); the first `keep_host`
+    keyframes also stay on the host for the CPU baseline."""
     from orbslam2_amd import synth
-    kfs = synth.keyframe_pool(seed=seed, n_kf=STORE_KF, n=N_FEAT, window=int(N_FEAT / 0.6))
-    return kfs, ctx.upload_frames(kfs)
+    ids, host = [], []
+    for s in range(0, n_kf, 250):
+        kfs = synth.keyframe_pool(seed=synth.SEED0 + 5 + s, n_kf=min(250, n_kf - s), n=N_FEAT, window=int(N_FEAT / 0.6))
+        ids.append(ctx.upload_frames(kfs))
+        if len(host) < keep_host:
+            host += kfs[: keep_host - len(host)]
+    return host, np.concatenate(ids).astype(np.int32)
 
 
 def pair_list(rng, ids, n_pairs):
-    """Pairs as an all-pairs tiling would produce them: neighbours (high overlap) and far keyframes mixed."""
+    """Pairs of a small store, neighbours (high overlap) and far keyframes mixed (secondary measurements)."""
     a = rng.integers(0, len(ids), n_pairs)
     d = np.where(rng.random(n_pairs) < 0.5, rng.integers(1, 4, n_pairs), rng.integers(4, len(ids), n_pairs))
     b = (a + d) % len(ids)
     return ids[a].astype(np.int32), ids[b].astype(np.int32)
 
 
-def cpu_baseline(kfs, seconds=12.0):
-    """Times the CPU oracle (reference SWAR popcount restatement) on a bounded sample of the same workload."""
-    from oracle import oracle_ffi as orc
-    orc.lib()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    rng = np.random.default_rng(7)
-    # single thread first (how the reference runs one matcher call)
-    t0 = time.perf_counter(); n1 = 0
-    while time.perf_counter() - t0 < seconds * 0.25:
-        i, j = rng.integers(0, len(kfs), 2)
-        orc.bf2nn(kfs[i], kfs[j], RATIO, TH)
-        n1 += 1
-    single = n1 * N_FEAT * N_FEAT / (time.perf_counter() - t0)
-    done = [0] * cores
-    stop = time.perf_counter() + seconds * 0.75
+def _all_cores(fn, cores, seconds):
+    """fn(k, rng) -> units done by one call, run on `cores` threads for `seconds` (ctypes releases the GIL): units / s"""
+    done = [0.0] * cores
+    stop = time.perf_counter() + seconds
 
     def work(k):
         r = np.random.default_rng(100 + k)
         while time.perf_counter() < stop:
-            i, j = r.integers(0, len(kfs), 2)
-            orc.bf2nn(kfs[i], kfs[j], RATIO, TH)   # ctypes releases the GIL
-            done[k] += 1
+            done[k] += fn(k, r)
 
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
     [t.start() for t in th]; [t.join() for t in th]
-    dt = time.perf_counter() - t0
-    multi = sum(done) * N_FEAT * N_FEAT / dt
-    # the same single-thread loop with hardware popcount (-mpopcnt path of the oracle), reported separately
+    return sum(done) / (time.perf_counter() - t0), sum(done)
+
+
+def cpu_baseline(kfs, n_store):
+    """The CPU oracle (restatement of the reference, SWAR popcount as ORBmatcher.cc:2184-2200) on the box's host cores,
+    bounded samples of the same workloads.  About 25 s in all."""
+    from oracle import oracle_ffi as orc
+    from orbslam2_amd import allpairs, synth
+    orc.lib()
+    flags = orc.timing_build() or "-O2 -msse2 -mpopcnt (prebuilt; no compiler on this machine)"
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    rng = np.random.default_rng(7)
+    nk = len(kfs)
+    per_pair = float(N_FEAT) * N_FEAT
+    # C2, one thread (how the reference runs one matcher call), SWAR then hardware popcount
+    t0 = time.perf_counter(); n1 = 0
+    while time.perf_counter() - t0 < 2.5:
+        i, j = rng.integers(0, nk, 2); orc.bf2nn(kfs[i], kfs[j], RATIO, TH); n1 += 1
+    single = n1 * per_pair / (time.perf_counter() - t0)
     orc.set_popcnt(True)
     t0 = time.perf_counter(); n2 = 0
-    while time.perf_counter() - t0 < 2.0:
-        i, j = rng.integers(0, len(kfs), 2)
-        orc.bf2nn(kfs[i], kfs[j], RATIO, TH)
-        n2 += 1
-    single_popcnt = n2 * N_FEAT * N_FEAT / (time.perf_counter() - t0)
+    while time.perf_counter() - t0 < 1.5:
+        i, j = rng.integers(0, nk, 2); orc.bf2nn(kfs[i], kfs[j], RATIO, TH); n2 += 1
+    single_popcnt = n2 * per_pair / (time.perf_counter() - t0)
     orc.set_popcnt(False)
-    # config 3 on one core, as the reference runs it (one SearchByProjection call, 50k map points, th = 3)
-    from orbslam2_amd import synth
+    # C2 / headline, all cores ("generous CPU": the reference runs every matcher call on one thread)
+    def bf(k, r):
+        i, j = r.integers(0, nk, 2); orc.bf2nn(kfs[i], kfs[j], RATIO, TH); return 1
+    multi_pairs_s, multi_pairs = _all_cores(bf, cores, 8.0)
+    # C3: one SearchByProjection call (50k map points, th = 3) on one core, then independent instances on all cores
     f, q = synth.proj_instance(seed=synth.SEED0 + 3, n=N_FEAT, n_queries=50000)
-    t1 = time.perf_counter()
-    orc.search_proj_points(f, q, 3.0, 0.8)
-    proj_ms = (time.perf_counter() - t1) * 1e3
-    # config 4, SearchByBoW(KF,KF) on one core over a sample of the pair list `extra.search_bow_kfkf_*` runs: time per pair and the
-    # distance evaluations the reference algorithm performs per pair (the oracle's counter, SURVEY 8(d))
-    ia, ib = pair_list(np.random.default_rng(3), np.arange(len(kfs)), 8192)
+    t1 = time.perf_counter(); orc.search_proj_points(f, q, 3.0, 0.8); proj_ms = (time.perf_counter() - t1) * 1e3
+    def proj(k, r):
+        orc.search_proj_points(f, q, 3.0, 0.8); return 1
+    proj_inst_s, _ = _all_cores(proj, cores, 2.0)
+    # C4: SearchByBoW(KF,KF) over the pair list `extra.search_bow_kfkf_*` runs: one core (time + the reference's distance
+    # evaluations per pair, the oracle's counter), then all cores, one pair per task
+    ia, ib = pair_list(np.random.default_rng(3), np.arange(nk), 8192)
     bow_cmps = 0
     t1 = time.perf_counter()
     for k in range(256):
         bow_cmps += orc.search_bow(1, kfs[ia[k]], kfs[ib[k]], 0.75, True)[2]
     bow_pair_ms = (time.perf_counter() - t1) * 1e3 / 256
-    # ComputeBoW of one frame on one core (descent of the synthetic k = 10, depth-6 tree; restated DBoW2 transform)
-    voc = synth.make_vocabulary_regular()
+    def bow(k, r):
+        j = int(r.integers(0, 8192)); orc.search_bow(1, kfs[ia[j]], kfs[ib[j]], 0.75, True); return 1
+    bow_pairs_s, _ = _all_cores(bow, cores, 2.0)
+    # C5: a 1/1000 random sample of the store's 10 122 750 pairs (regenerated on the host: only the sampled keyframes'
+    # chunks), SearchByBoW(KF,KF) on all cores; the brute-force variant on a 1/10000 sample; both EXTRAPOLATED to the triangle
+    n_pairs_all = n_store * (n_store - 1) // 2
+    srng = np.random.default_rng(5)
+    sa = srng.integers(0, n_store, max(1, n_pairs_all // 1000)); sb = srng.integers(0, n_store, len(sa))
+    keep = sa != sb; sa, sb = sa[keep], sb[keep]
+    chunks = {}
+    def kf_of(i):
+        c = int(i) // 250
+        if c not in chunks:
+            chunks[c] = synth.keyframe_pool(seed=synth.SEED0 + 5 + c * 250, n_kf=min(250, n_store - c * 250), n=N_FEAT, window=int(N_FEAT / 0.6))
+        return chunks[c][int(i) % 250]
     t1 = time.perf_counter()
-    orc.transform(voc, kfs[0].desc, 4)
-    bow_ms = (time.perf_counter() - t1) * 1e3
-    return {"value": round(multi / 1e9, 4), "unit": "G Hamming cmps/s", "cores": cores, "kind": "port",
+    sample = [(kf_of(a), kf_of(b)) for a, b in zip(sa[:4000], sb[:4000])]       # bounded: host generation is the slow part
+    gen_s = time.perf_counter() - t1
+    pos = [0]; lock = threading.Lock()
+    def c5(kind):
+        def fn(k, r):
+            with lock:
+                j = pos[0]; pos[0] += 1
+            a, b = sample[j % len(sample)]
+            if kind == "bow":
+                orc.search_bow(1, a, b, 0.75, True)
+            else:
+                orc.bf2nn(a, b, RATIO, TH)
+            return 1
+        return fn
+    c5_bow_s, c5_bow_n = _all_cores(c5("bow"), cores, 2.0)
+    pos[0] = 0
+    c5_bf_s, c5_bf_n = _all_cores(c5("bf"), cores, 3.0)
+    return {"value": round(multi_pairs_s * per_pair / 1e9, 4), "unit": "G Hamming cmps/s", "cores": cores, "kind": "port",
+            "build": "g++ " + flags, "pairs_per_s": round(multi_pairs_s, 1),
             "single_thread_value": round(single / 1e9, 4), "single_thread_hw_popcnt_value": round(single_popcnt / 1e9, 4),
-            "search_by_projection_single_instance_ms": round(proj_ms, 3), "compute_bow_single_frame_ms": round(bow_ms, 3),
+            "search_by_projection_single_instance_ms": round(proj_ms, 3),
+            "search_by_projection_all_cores_instances_per_s": round(proj_inst_s, 1),
+            "search_by_projection_all_cores_queries_per_s": round(proj_inst_s * 50000, 1),
             "search_bow_kfkf_ms_per_pair": round(bow_pair_ms, 4), "search_bow_kfkf_cmps_per_pair": round(bow_cmps / 256, 1),
-            "sample": f"{sum(done)} random keyframe pairs of the bench store ({N_FEAT}x{N_FEAT} brute-force 2-NN, SWAR popcount "
-                      f"as ORBmatcher.cc:2184-2200), {cores} threads x {seconds * 0.75:.0f} s; single thread {n1} pairs"}
+            "search_bow_kfkf_all_cores_pairs_per_s": round(bow_pairs_s, 1),
+            "c5_all_pairs_search_bow_all_cores_pairs_per_s": round(c5_bow_s, 1),
+            "c5_all_pairs_search_bow_extrapolated_s": round(n_pairs_all / c5_bow_s, 1),
+            "c5_all_pairs_brute_force_all_cores_pairs_per_s": round(c5_bf_s, 1),
+            "c5_all_pairs_brute_force_extrapolated_s": round(n_pairs_all / c5_bf_s, 1),
+            "c5_note": f"EXTRAPOLATED from random pairs of the {n_store}-keyframe store ({int(c5_bow_n)} SearchByBoW, {int(c5_bf_n)} brute-force "
+                       f"calls over a {len(sample)}-pair sample, {cores} threads) to its {n_pairs_all} pairs; host generation of the sample {gen_s:.1f} s not counted",
+            "sample": f"{int(multi_pairs)} random keyframe pairs of the store's first {nk} keyframes ({N_FEAT}x{N_FEAT} brute-force 2-NN, SWAR popcount "
+                      f"as ORBmatcher.cc:2184-2200), {cores} threads x 8 s ('generous CPU': the reference runs a matcher call on one thread); "
+                      f"single thread {n1} pairs"}
 
 
 def popcount_form(ctx, torch, dev, ids):
@@ -120,33 +183,34 @@ def popcount_form(ctx, torch, dev, ids):
     BASELINE's north star describes, priced against the integer-popcount roofline."""
     from orbslam2_amd import _lib
     L = _lib.load()
-    fa, fb = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
+    P = 4096
+    fa, fb = pair_list(np.random.default_rng(11), ids, P)
     tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
-    m = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
+    m = torch.empty((P, N_FEAT), dtype=torch.int32, device=dev); c = torch.empty(P, dtype=torch.int32, device=dev)
     ms = []
     try:
         L.orbm__bf2nn_variant(11)
         for rep in range(6):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ctx.bf2nn_dev(PAIRS_PER_STEP, tfa.data_ptr(), tfb.data_ptr(), RATIO, TH, N_FEAT, m.data_ptr(), None, None, c.data_ptr())
+            ctx.bf2nn_dev(P, tfa.data_ptr(), tfb.data_ptr(), RATIO, TH, N_FEAT, m.data_ptr(), None, None, c.data_ptr())
             e1.record(); torch.cuda.synchronize()
             if rep:
                 ms.append(e0.elapsed_time(e1))
     finally:
         L.orbm__bf2nn_variant(0)
     kms = float(np.mean(ms))
-    tcmps = PAIRS_PER_STEP * float(N_FEAT) * N_FEAT / (kms * 1e-3) / 1e12
+    tcmps = P * float(N_FEAT) * N_FEAT / (kms * 1e-3) / 1e12
     return {"bound": "valu-int-popcount", "kernel": "bf2nn_kernel<2,4,0>", "kernel_ms": round(kms, 4), "achieved": round(tcmps, 4),
             "peak": round(PEAK_TCMPS, 4), "unit": "T Hamming cmps/s", "frac": round(tcmps / PEAK_TCMPS, 4),
-            "pairs_per_s": round(PAIRS_PER_STEP / (kms * 1e-3), 1),
+            "pairs_per_s": round(P / (kms * 1e-3), 1),
             "frac_of_survey_peak": round(tcmps / 2.4576, 4),
-            "note": "peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cycles + 8 bcnt x 4 cycles) per comparison (issue rates "
-                    "measured with scripts/ubench_valu*.hip: v_xor is double-rate); SURVEY 8(d) prices all 16 lane-ops at 64 lanes/clk/CU "
-                    "= 2.4576 T cmps/s (frac_of_survey_peak)"}
+            "note": "4096 mixed pairs of the store's first 96 keyframes; peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (8 xor x 2 cycles + 8 bcnt x 4 "
+                    "cycles) per comparison (issue rates measured with scripts/ubench_valu*.hip: v_xor is double-rate); SURVEY 8(d) prices all "
+                    "16 lane-ops at 64 lanes/clk/CU = 2.4576 T cmps/s (frac_of_survey_peak)"}
 
 
-def secondary(ctx, torch, dev, kfs, ids):
+def secondary(ctx, torch, dev, ids):
     """Short measurements of the other kernels (parity-tested configs 3/4), reported in `extra`."""
     from orbslam2_amd import synth
     out = {}
@@ -156,33 +220,36 @@ def secondary(ctx, torch, dev, kfs, ids):
     fa, fb = pair_list(rng, ids, 8192)
     tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
     match = torch.empty((8192, N_FEAT), dtype=torch.int32, device=dev); counts = torch.empty(8192, dtype=torch.int32, device=dev)
-    for rep in range(3):
+    best = 1e30
+    for rep in range(4):
         e0, e1 = ev(), ev(); e0.record()
         ctx.search_bow_dev(1, 8192, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, N_FEAT, match.data_ptr(), counts.data_ptr())
         e1.record(); torch.cuda.synchronize()
-    out["search_bow_kfkf_pairs_per_s"] = round(8192 / (e0.elapsed_time(e1) * 1e-3), 1)
+        if rep:
+            best = min(best, e0.elapsed_time(e1))
+    out["search_bow_kfkf_pairs_per_s"] = round(8192 / (best * 1e-3), 1)
     # config 2 again with two more forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount with early
-    # abandon (ORBMATCH_BF2NN_EARLY_ABANDON=1: the last 64 bits of a comparison are skipped when the first 192 already
-    # reach the tracking bound, so not every distance is evaluated in full) and the int8 MFMA form
+    # abandon and the int8 MFMA form
     from orbslam2_amd import _lib
     L = _lib.load()
-    fa2, fb2 = pair_list(np.random.default_rng(11), ids, PAIRS_PER_STEP)
+    P2 = 4096
+    fa2, fb2 = pair_list(np.random.default_rng(11), ids, P2)
     tfa2 = torch.tensor(fa2, device=dev); tfb2 = torch.tensor(fb2, device=dev)
-    m2 = torch.empty((PAIRS_PER_STEP, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(PAIRS_PER_STEP, dtype=torch.int32, device=dev)
+    m2 = torch.empty((P2, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(P2, dtype=torch.int32, device=dev)
     for variant, name in ((8, "valu_early_abandon"), (9, "mfma_int8")):
         try:
             L.orbm__bf2nn_variant(variant)
             best = 1e30
             for rep in range(4):
                 e0, e1 = ev(), ev(); e0.record()
-                ctx.bf2nn_dev(PAIRS_PER_STEP, tfa2.data_ptr(), tfb2.data_ptr(), RATIO, TH, N_FEAT, m2.data_ptr(), None, None, c2.data_ptr())
+                ctx.bf2nn_dev(P2, tfa2.data_ptr(), tfb2.data_ptr(), RATIO, TH, N_FEAT, m2.data_ptr(), None, None, c2.data_ptr())
                 e1.record(); torch.cuda.synchronize()
                 if rep:
                     best = min(best, e0.elapsed_time(e1))
         finally:
             L.orbm__bf2nn_variant(0)
-        out[f"bf2nn_{name}_pairs_per_s"] = round(PAIRS_PER_STEP / (best * 1e-3), 1)
-        out[f"bf2nn_{name}_Gcmps"] = round(PAIRS_PER_STEP * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
+        out[f"bf2nn_{name}_pairs_per_s"] = round(P2 / (best * 1e-3), 1)
+        out[f"bf2nn_{name}_Gcmps"] = round(P2 * N_FEAT * N_FEAT / (best * 1e-3) / 1e9, 1)
     # config 4 as stated: ONE frame against 64 candidate keyframes (relocalisation / loop closure), SearchByBoW(KF, F)
     cand = ids[rng.choice(len(ids), 64, replace=False)].astype(np.int32)
     tca = torch.tensor(cand, device=dev); tcb = torch.tensor(np.full(64, ids[0], np.int32), device=dev)
@@ -229,8 +296,8 @@ def secondary(ctx, torch, dev, kfs, ids):
             out["search_by_projection_single_instance_ms"] = round(best, 4)
     ctx.free_frames(fid); ctx.free_queries(qid)
     # ComputeBoW on the device: descent of a k = 10, depth-6 tree (ORBvoc.txt's shape, 1.1 M nodes, synthetic) with every
-    # descriptor of the store's keyframes + FeatureVector build, in one call; then one frame alone
-    import time
+    # descriptor of 96 keyframes + FeatureVector build, in one call; then one frame alone.  (Runs last: it replaces the
+    # FeatureVectors of these keyframes with those of the synthetic tree.)
     vid = ctx.upload_vocabulary(synth.make_vocabulary_regular())
     for nfr in (len(ids), 1):
         best = 1e30
@@ -258,22 +325,41 @@ def secondary(ctx, torch, dev, kfs, ids):
     out["bow_l1_score_pairs_per_s"] = round(4096 / (best * 1e-3), 1)
     out["bow_l1_score_4096_keyframes_ms"] = round(best, 4)
     ctx.free_bowvecs(bid)
-    # the store's keyframes got FeatureVectors of the synthetic tree: nothing after this point uses them
     return out
+
+
+def full_triangle(ctx, torch, dev, fa_all, fb_all, pid_all, summ, lists, kind):
+    """Config 5 as stated, on this one GPU: every pair of the store once (extra; the N-GPU job is this loop over each rank's shard)."""
+    n = fa_all.numel()
+    P = PAIRS_PER_LAUNCH
+    acc = torch.zeros((), dtype=torch.int64, device=dev); tot = torch.zeros((), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for s in range(0, n, P):
+        e = min(n, s + P)
+        ctx.allpairs_batch_dev(kind, e - s, fa_all.data_ptr() + 4 * s, fb_all.data_ptr() + 4 * s, pid_all.data_ptr() + 4 * s, 0.75, TH, True,
+                               N_FEAT, ACCEPT, summ.data_ptr(), lists.data_ptr(), LIST_CAP, summ.data_ptr() + 8 * P)
+        hdr = summ[P]
+        acc += hdr & 0xFFFFFFFF; tot += hdr >> 32
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, int(acc), int(tot)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_STEP)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_LAUNCH, help="pairs per launch")
+    ap.add_argument("--launches", type=int, default=LAUNCHES_PER_STEP, help="launches per step")
+    ap.add_argument("--keyframes", type=int, default=STORE_KF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
+    from orbslam2_amd import allpairs
     from orbslam2_amd.matcher import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -294,123 +380,182 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     ctx = Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    kfs, ids = build_store(ctx, seed=20161013)           # same store on every rank (replicated, 6 MB)
-    rng = np.random.default_rng(1000 + rank)              # every rank matches its own pairs
-    P = args.pairs
-    fa, fb = pair_list(rng, ids, P)
-    tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
-    match = [torch.empty((P, N_FEAT), dtype=torch.int32, device=dev) for _ in range(2)]
-    counts = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(2)]
-    packed = [torch.empty((P, N_FEAT + 2), dtype=torch.int16, device=dev) for _ in range(2)]
-    gather_bufs = None
-    rec_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1 and rank == 0:
-        # records travel as bytes: neither NCCL/RCCL nor gloo has an int16 datatype
-        gather_bufs = [[torch.empty(packed[0].view(torch.uint8).shape, dtype=torch.uint8, device=rec_dev) for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
-    kern_ms = []
+    n_kf = args.keyframes
+    t_setup = time.perf_counter()
+    kfs, ids = build_store(ctx, n_kf)                       # same store on every rank (replicated)
+    ctx.bf2nn_prepare()                                     # +-1 images of every keyframe: launches below only enqueue
+    P, L = args.pairs, args.launches
+    pa, pb = allpairs.shard_pairs(n_kf, rank, world, TILE)  # this rank's block-cyclic share of the triangle
+    n_mine = len(pa)
+    if n_mine < P:
+        raise SystemExit(f"rank {rank}: shard of {n_mine} pairs is shorter than one launch of {P}")
+    tid = torch.tensor(ids, device=dev)
+    fa_all = tid[torch.tensor(pa, device=dev).long()].contiguous()
+    fb_all = tid[torch.tensor(pb, device=dev).long()].contiguous()
+    pid_all = torch.tensor(allpairs.pair_ids(pa, pb, n_kf).view(np.int32), device=dev)
+    n_full = n_mine // P                                    # whole launches in the shard; launch j takes window j % n_full
+    setup_s = time.perf_counter() - t_setup
+    summ = [torch.empty(P + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    lists = [torch.empty(LIST_CAP, dtype=torch.int32, device=dev) for _ in range(2)]
+    hdr_pin = [torch.empty(1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    done_ev = [torch.cuda.Event() for _ in range(2)]
+    comm_ev = [None, None]
+    comm_stream = torch.cuda.Stream(device=dev)
+    compute_stream = torch.cuda.current_stream()
+    n_launch_total = (args.steps + args.warmup) * L
+    # rank 0 keeps what arrives: every summary of the run, lists in a ring
+    sink_summ = torch.empty(n_launch_total * world * P, dtype=torch.int64, device=comm_dev) if rank == 0 else None
+    SINK_LISTS = 1 << 26
+    sink_lists = torch.empty(SINK_LISTS, dtype=torch.int32, device=comm_dev) if rank == 0 else None
+    sink = {"summ": 0, "lists": 0, "entries": 0, "bytes_wire": 0, "overflow": 0}
 
-    def step(k, timed):
-        b = k & 1
-        if pending[b] is not None:
-            pending[b].wait(); pending[b] = None
+    def take(r, s_t, l_t):
+        n = s_t.numel()
+        sink_summ[sink["summ"]: sink["summ"] + n].copy_(s_t, non_blocking=True); sink["summ"] += n
+        m = l_t.numel()
+        if m:
+            if sink["lists"] + m > SINK_LISTS:
+                sink["lists"] = 0
+            sink_lists[sink["lists"]: sink["lists"] + m].copy_(l_t, non_blocking=True); sink["lists"] += m
+        sink["entries"] += m
+        if r:
+            sink["bytes_wire"] += 8 * (n + 1) + 4 * m
+
+    ex = allpairs.RecordExchange(torch, dist, rank, world, P, comm_dev, take if rank == 0 else None, LIST_CAP)
+    kern_ev = []
+    pending = []
+
+    def launch(j, timed):
+        b = j & 1
+        if comm_ev[b] is not None:
+            compute_stream.wait_event(comm_ev[b])           # the records of launch j - 2 have left these buffers
+        s = (j % n_full) * P
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        ctx.bf2nn_dev(P, tfa.data_ptr(), tfb.data_ptr(), RATIO, TH, N_FEAT, match[b].data_ptr(), None, None, counts[b].data_ptr())
+        ctx.allpairs_batch_dev(0, P, fa_all.data_ptr() + 4 * s, fb_all.data_ptr() + 4 * s, pid_all.data_ptr() + 4 * s, RATIO, TH, True,
+                               N_FEAT, ACCEPT, summ[b].data_ptr(), lists[b].data_ptr(), LIST_CAP, summ[b].data_ptr() + 8 * P)
         e1.record()
+        hdr_pin[b].copy_(summ[b][P:], non_blocking=True)
+        done_ev[b].record()
         if timed:
-            kern_ms.append((e0, e1))
-        if world > 1:
-            # match list record per pair: 2000 x int16 candidate index (-1 = none) + the int32 count
-            packed[b][:, :N_FEAT] = match[b]
-            packed[b][:, N_FEAT:] = counts[b].view(torch.int16).view(P, 2)
-            rec = packed[b].view(torch.uint8)
-            if backend != "nccl":
-                rec = rec.cpu()
-            pending[b] = dist.gather(rec, gather_bufs[b] if rank == 0 else None, dst=0, async_op=True)
+            kern_ev.append((e0, e1))
 
-    def drain():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait(); pending[b] = None
+    def ship(j):
+        """records of launch j -> rank 0, on the communication stream (launch j + 1 is already queued on the compute stream)"""
+        b = j & 1
+        done_ev[b].synchronize()
+        entries = int(hdr_pin[b].item()) >> 32
+        if entries > LIST_CAP:
+            sink["overflow"] += 1
+            entries = LIST_CAP
+        with torch.cuda.stream(comm_stream):
+            s_t, l_t = summ[b], lists[b]
+            if comm_dev.type == "cpu":
+                s_t, l_t = s_t.cpu(), l_t[:entries].cpu()
+            ex.submit(s_t, l_t, entries)
+            comm_ev[b] = torch.cuda.Event(); comm_ev[b].record()
 
-    for k in range(args.warmup):
-        step(k, False)
-    drain()
+    def run(first, n):
+        for j in range(first, first + n):
+            launch(j, first >= args.warmup * L)
+            if j > first:
+                ship(j - 1)
+        ship(first + n - 1)
+        comm_stream.synchronize()
+
+    run(0, args.warmup * L)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, True)
-    drain()
+    run(args.warmup * L, args.steps * L)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=rec_dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kms = float(np.mean([a.elapsed_time(b) for a, b in kern_ms])) if kern_ms else float("nan")
+    kms = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) if kern_ev else float("nan")
     cmps_per_launch = float(P) * N_FEAT * N_FEAT
-    total_cmps = cmps_per_launch * args.steps * world
+    pairs_total = float(P) * L * args.steps * world
     if rank == 0:
         achieved_tcmps = cmps_per_launch / (kms * 1e-3) / 1e12
         achieved = achieved_tcmps * FLOP_PER_CMP
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_bf2nn_traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        got = sink_summ[: sink["summ"]]
+        n_valid = int((got & 0xFFFFFFFF != 0xFFFFFFFF).sum())
+        matches_seen = int(((got >> 32) & 0xFFFF).sum())
         res = {
             "metric": "G Hamming cmps/s + keyframe-pairs matched/s (2k feats/frame), 1/2/4/8 GPUs",
-            "value": round(total_cmps / dt / 1e9, 2),
+            "value": round(pairs_total * N_FEAT * N_FEAT / dt / 1e9, 2),
             "unit": "G Hamming cmps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp4-mx (+-1 per descriptor bit, exact) x fp4-mx -> f32 accumulate (exact integers)", "data": "synthetic",
             "config": {"workload": "brute-force 2-NN Hamming + TH_LOW + ratio test, 2000x2000 256-bit descriptors per keyframe pair "
-                                   "(BASELINE configs[1]), batched", "pairs_per_step_per_gpu": P, "store_keyframes": STORE_KF,
-                       "features_per_keyframe": N_FEAT, "ratio": RATIO, "th": TH,
-                       "parallelism": f"pairs sharded over {world} rank(s), RCCL gather of match lists to rank 0" if world > 1 else "1 GPU"},
-            "pairs_per_s": round(P * args.steps * world / dt, 1),
+                                   "(BASELINE configs[1]), batched over the pair triangle of the config-5 store (BASELINE configs[4])",
+                       "store_keyframes": n_kf, "features_per_keyframe": N_FEAT, "pairs_in_triangle": n_kf * (n_kf - 1) // 2,
+                       "pairs_per_launch": P, "launches_per_step": L, "pairs_per_step_per_gpu": P * L, "ratio": RATIO, "th": TH,
+                       "accept_threshold": ACCEPT, "tile": TILE,
+                       "parallelism": (f"pair triangle dealt block-cyclically ({TILE}x{TILE} keyframe tiles) to {world} ranks, store replicated, "
+                                       f"compact records to rank 0 over RCCL (gather of summaries + point-to-point lists) on a second stream")
+                                      if world > 1 else "1 GPU (rank 0's shard = the whole triangle)"},
+            "pairs_per_s": round(pairs_total / dt, 1),
+            "timed_region_s": round(dt, 4),
+            "records": {"pairs_received": n_valid, "matches_in_summaries": matches_seen, "list_entries_received": sink["entries"],
+                        "bytes_over_the_wire": sink["bytes_wire"],
+                        "wire_bytes_per_remote_pair": round(sink["bytes_wire"] / max(1, n_valid * (world - 1) / world), 2) if world > 1 else 0.0,
+                        "record_bytes_per_pair": round((8 * n_valid + 4 * sink["entries"]) / max(1, n_valid), 2),
+                        "list_buffer_overflows": sink["overflow"],
+                        "shard_pairs_rank0": n_mine, "shard_wraps": round(n_launch_total / n_full, 2)},
+            "setup_s": round(setup_s, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_MFMA_TFLOPS, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
                          "kernel": "bf2nn_mfma4_kernel<false,0,2>", "kernel_ms": round(kms, 4),
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
                          "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
-                                 "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz; "
-                                 "the chip holds about 1.5-2.0 GHz in MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back). "
+                                 "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "
+                                 "kernel_ms = HIP events around one orbm_allpairs_batch call on its stream, averaged over the timed "
+                                 "region: the matching kernel plus its counter memset and the two record-compaction kernels "
+                                 "(profiles/: < 1 % of it), so `achieved` is a slight under-statement of the kernel alone. traffic: "
+                                 "not measurable inside this run (PMC counters need rocprofv3); profiles/r02_* holds the counter pass. "
                                  "vs_integer_popcount_roofline = achieved cmps/s over the 3.277 T cmps/s that bound the xor + popcount "
-                                 "form of this kernel (roofline_popcount_form: that form, same workload, same run). scripts/ubench_mfma4*.hip "
-                                 "(profiles/r01_ubench_mfma4.txt): back-to-back MFMAs on +-1 operands sustain 0.75-0.85 of this peak "
-                                 "(power), this kernel's loop structure in isolation 0.54"},
+                                 "form of this kernel (roofline_popcount_form: that form, same run)"},
         }
         res["roofline"]["vs_integer_popcount_roofline"] = round(achieved_tcmps / PEAK_TCMPS, 3)
+        small = ids[:SMALL_KF]
         try:
-            res["roofline_popcount_form"] = popcount_form(ctx, torch, dev, ids)
+            res["roofline_popcount_form"] = popcount_form(ctx, torch, dev, small)
         except Exception as e:
             res["roofline_popcount_form"] = {"error": repr(e)}
         if not args.no_extra:
             try:
-                res["extra"] = secondary(ctx, torch, dev, kfs, ids)
+                ex_out = {}
+                if world == 1:
+                    for kind, name in ((1, "search_bow"), (0, "brute_force")):
+                        s_dt, s_acc, s_ent = full_triangle(ctx, torch, dev, fa_all, fb_all, pid_all, summ[0], lists[0], kind)
+                        ex_out[f"c5_all_pairs_{name}_s"] = round(s_dt, 3)
+                        ex_out[f"c5_all_pairs_{name}_pairs_per_s"] = round(n_mine / s_dt, 1)
+                        ex_out[f"c5_all_pairs_{name}_accepted_pairs"] = s_acc
+                        ex_out[f"c5_all_pairs_{name}_record_bytes_per_pair"] = round((8 * n_mine + 4 * s_ent) / n_mine, 2)
+                ex_out.update(secondary(ctx, torch, dev, small))
+                res["extra"] = ex_out
             except Exception as e:  # secondary numbers must never break the headline line
                 res["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(kfs)
-            ex, cb = res.get("extra", {}), res["cpu_baseline"]
-            if "search_bow_kfkf_pairs_per_s" in ex:   # BoW-grouped search in the metric's other unit: the reference's evaluations/s
-                ex["search_bow_kfkf_Gcmps"] = round(ex["search_bow_kfkf_pairs_per_s"] * cb["search_bow_kfkf_cmps_per_pair"] / 1e9, 2)
+            res["cpu_baseline"] = cpu_baseline(kfs, n_kf)
+            ex_d, cb = res.get("extra", {}), res["cpu_baseline"]
+            if "search_bow_kfkf_pairs_per_s" in ex_d:   # BoW-grouped search in the metric's other unit: the reference's evaluations/s
+                ex_d["search_bow_kfkf_Gcmps"] = round(ex_d["search_bow_kfkf_pairs_per_s"] * cb["search_bow_kfkf_cmps_per_pair"] / 1e9, 2)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

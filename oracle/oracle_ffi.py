@@ -25,37 +25,58 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def timing_build():
+    """CPU-baseline build (bench.py only): the same source with -O3 -march=native -ffp-contract=off, compiled on the
+    machine that runs it (the committed -O2 -msse2 library stays the parity checker) and made the library in use.
+    Returns the flags, or None if no compiler is there (the -O2 build stays in use)."""
+    import tempfile
+    global _lib
+    flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+    out = os.path.join(tempfile.gettempdir(), f"liborb_oracle_native_{os.getuid()}_{os.getpid()}.so")
+    try:
+        subprocess.check_call(["g++", *flags, "-shared", "-o", out, os.path.join(_HERE, "orb_oracle.cpp")], timeout=300,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = _bind(C.CDLL(out))
+        os.unlink(out)
+        return " ".join(flags)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
-        u8p, i32p, u32p, f32p = (C.POINTER(t) for t in (C.c_uint8, C.c_int32, C.c_uint32, C.c_float))
-        u64p = C.POINTER(C.c_uint64)
-        FV, PQ, WQ = C.POINTER(CFrameView), C.POINTER(CProjQueries), C.POINTER(CWinQueries)
-        L.orc_set_popcnt.argtypes = [C.c_int]
-        L.orc_hamming256.argtypes = [u8p, u8p]
-        L.orc_hamming256_popcnt.argtypes = [u8p, u8p]
-        L.orc_three_maxima.argtypes = [i32p, C.c_int, i32p]
-        L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
-        L.orc_build_grid.argtypes = [FV, u32p, u32p]
-        L.orc_features_in_area.argtypes = [FV, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, i32p]
-        L.orc_bf2nn.argtypes = [FV, FV, C.c_float, C.c_int, i32p, i32p, i32p, u64p]
-        L.orc_search_bow.argtypes = [C.c_int, FV, FV, C.c_float, C.c_int, i32p, u64p]
-        L.orc_search_triang.argtypes = [FV, FV, f32p, f32p, C.c_int, C.c_int, i32p, u64p]
-        L.orc_search_proj_points.argtypes = [FV, PQ, C.c_float, C.c_float, u8p, i32p, u64p]
-        L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
-        L.orc_search_window_free.argtypes = [FV, WQ, C.c_int, C.c_int, i32p, u64p]
-        L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
-        L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
-        L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
-        L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p, i32p, u32p, C.POINTER(C.c_double)]
-        L.orc_bow_score.argtypes = [C.POINTER(CBowVecView), C.POINTER(CBowVecView), i32p]
-        L.orc_bow_score.restype = C.c_double
-        L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
-        _lib = L
+        _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def _bind(L):
+    u8p, i32p, u32p, f32p = (C.POINTER(t) for t in (C.c_uint8, C.c_int32, C.c_uint32, C.c_float))
+    u64p = C.POINTER(C.c_uint64)
+    FV, PQ, WQ = C.POINTER(CFrameView), C.POINTER(CProjQueries), C.POINTER(CWinQueries)
+    L.orc_set_popcnt.argtypes = [C.c_int]
+    L.orc_hamming256.argtypes = [u8p, u8p]
+    L.orc_hamming256_popcnt.argtypes = [u8p, u8p]
+    L.orc_three_maxima.argtypes = [i32p, C.c_int, i32p]
+    L.orc_rot_bin.argtypes = [C.c_float, C.c_float]
+    L.orc_build_grid.argtypes = [FV, u32p, u32p]
+    L.orc_features_in_area.argtypes = [FV, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, i32p]
+    L.orc_bf2nn.argtypes = [FV, FV, C.c_float, C.c_int, i32p, i32p, i32p, u64p]
+    L.orc_search_bow.argtypes = [C.c_int, FV, FV, C.c_float, C.c_int, i32p, u64p]
+    L.orc_search_triang.argtypes = [FV, FV, f32p, f32p, C.c_int, C.c_int, i32p, u64p]
+    L.orc_search_proj_points.argtypes = [FV, PQ, C.c_float, C.c_float, u8p, i32p, u64p]
+    L.orc_search_window.argtypes = [C.c_int, FV, WQ, C.c_int, C.c_int, u8p, i32p, u64p]
+    L.orc_search_window_free.argtypes = [FV, WQ, C.c_int, C.c_int, i32p, u64p]
+    L.orc_search_init.argtypes = [FV, FV, f32p, C.c_int, C.c_float, C.c_int, i32p, u64p]
+    L.orc_stereo_match.argtypes = [FV, FV, C.c_int, C.c_float, i32p, i32p, u64p]
+    L.orc_distinctive_descriptor.argtypes = [u8p, C.c_int]
+    L.orc_transform.argtypes = [C.POINTER(CVocabView), u8p, C.c_int, C.c_int, i32p, i32p, u32p, u32p, u32p, i32p, u32p, C.POINTER(C.c_double)]
+    L.orc_bow_score.argtypes = [C.POINTER(CBowVecView), C.POINTER(CBowVecView), i32p]
+    L.orc_bow_score.restype = C.c_double
+    L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+    return L
 
 
 def _p(a, t):

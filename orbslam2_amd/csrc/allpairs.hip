@@ -62,7 +62,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void pack_scan_kernel(int n_pairs, co
 __global__ __launch_bounds__(256) void pack_lists_kernel(int n_pairs, const int32_t *__restrict__ counts,
                                                          const int32_t *__restrict__ match, int stride,
                                                          const uint32_t *__restrict__ list_off, uint32_t *__restrict__ lists,
-                                                         uint32_t list_cap) {
+                                                         uint32_t list_cap, const FrameDev *__restrict__ table,
+                                                         const int32_t *__restrict__ row_frame) {
     const int lane = threadIdx.x & 63;
     const int p = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (p >= n_pairs) return;
@@ -70,10 +71,12 @@ __global__ __launch_bounds__(256) void pack_lists_kernel(int n_pairs, const int3
     if (off == 0xFFFFFFFFu) return;                                              // not accepted (or padding)
     const int c = counts[p];
     const gptr<const int32_t> row = in_global(match) + (size_t)p * stride;
+    // the searches write rows [0, n) of the frame that indexes the row; beyond that the buffer is only defined when the caller says so
+    const int len = table ? min(stride, table[row_frame[p]].n) : stride;
     uint32_t pos = 0;
-    for (int i0 = 0; i0 < stride && pos < (uint32_t)c; i0 += 64) {
+    for (int i0 = 0; i0 < len && pos < (uint32_t)c; i0 += 64) {
         const int i = i0 + lane;
-        const int m = i < stride ? row[i] : -1;
+        const int m = i < len ? row[i] : -1;
         const bool ok = m >= 0;
         const unsigned long long mask = __ballot(ok);
         const uint32_t k = pos + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -133,7 +136,8 @@ int orbm_pack_records(orbm_ctx *ctx, int n_pairs, const uint32_t *pair_id, const
                        threshold, (uint2 *)dsum, list_off, (uint32_t *)dtot);
     if (n_pairs > 0 && list_cap > 0)
         hipLaunchKernelGGL(pack_lists_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, ctx->stream, n_pairs, (const int32_t *)dcnt,
-                           (const int32_t *)dmatch, stride, (const uint32_t *)list_off, (uint32_t *)dlists, list_cap);
+                           (const int32_t *)dmatch, stride, (const uint32_t *)list_off, (uint32_t *)dlists, list_cap,
+                           (const FrameDev *)nullptr, (const int32_t *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }
@@ -178,8 +182,6 @@ int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *fra
         (rc = io.out(summaries, P * 8, &dsum)) || (rc = io.out(lists, (size_t)list_cap * 4, &dlists)) || (rc = io.out(totals, 8, &dtot)))
         return rc;
     if (n_pairs > 0) {
-        // rows of frames shorter than the stride must read as "no match" for the packer
-        if (rows) HIPCHK(ctx, hipMemsetAsync(d_match, 0xFF, rows * 4, ctx->stream));
         if (kind == 0)
             rc = orbm_bf2nn_batch(ctx, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, th, stride, d_match, nullptr, nullptr, d_counts, 1);
         else
@@ -193,7 +195,8 @@ int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *fra
                        threshold, (uint2 *)dsum, list_off, (uint32_t *)dtot);
     if (n_pairs > 0 && list_cap > 0)
         hipLaunchKernelGGL(pack_lists_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, ctx->stream, n_pairs, (const int32_t *)d_counts,
-                           (const int32_t *)d_match, stride, (const uint32_t *)list_off, (uint32_t *)dlists, list_cap);
+                           (const int32_t *)d_match, stride, (const uint32_t *)list_off, (uint32_t *)dlists, list_cap,
+                           (const FrameDev *)ctx->d_frames, (const int32_t *)(kind == 2 ? dfb : dfa));   // rows beyond the frame's n are never read
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }
