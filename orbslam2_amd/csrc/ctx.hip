@@ -257,61 +257,10 @@ __global__ __launch_bounds__(GRID_THREADS) void build_grid_kernel(const FrameDev
     for (uint32_t i = tid; i < total; i += GRID_THREADS) {
         const uint32_t k = in_lds ? (uint32_t)lidx[i] : f.cell_idx[i];
         if (in_lds) f.cell_idx[i] = k;
-        ((gptr<v4f>)f.cell_rec)[i] = v4f{f.x[k], f.y[k], f.uright[k], __uint_as_float(k | ((uint32_t)f.octave[k] << 16))};
-    }
-    // skip lists over the cell-ordered stream, one per octave pair {p-1, p}: suffix "first match at or after j".
-    // Each thread owns a run of consecutive positions; the carry from the runs to its right is a suffix-min.
-    if (f.cell_nxt && in_lds) {
-        uint16_t *firstm = reinterpret_cast<uint16_t *>(cnt);       // [waves][8], cnt is free now
-        uint8_t *loct = reinterpret_cast<uint8_t *>(off);           // octave per stream position; off is free now (total is in a register)
-        __syncthreads();
-        for (uint32_t i = tid; i < total; i += GRID_THREADS) loct[i] = f.octave[lidx[i]];
-        __syncthreads();
-        const int per = ((int)total + GRID_THREADS) / GRID_THREADS;                    // positions 0..total-1 (+ the sentinel row `total`)
-        const int j0 = tid * per, j1 = min((int)total, j0 + per);
-        uint32_t fm[8];
-#pragma unroll
-        for (int p2 = 0; p2 < 8; p2++) fm[p2] = 0xFFFFu;
-        for (int j = j1 - 1; j >= j0; j--) {
-            const int o = loct[j];
-#pragma unroll
-            for (int p2 = 0; p2 < 8; p2++) if (o == p2 || o == p2 - 1) fm[p2] = (uint32_t)j;
-        }
-        // exclusive suffix-min of fm over the threads (positions grow with tid, so the min is the nearest match)
-        uint32_t carry[8];
-        const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-        for (int p2 = 0; p2 < 8; p2++) {
-            uint32_t v = fm[p2];                                    // inclusive suffix-min inside the wave
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_down(v, d, 64);
-                if (lane + d < 64) v = min(v, o);
-            }
-            if (lane == 0) firstm[wv * 8 + p2] = (uint16_t)v;       // the wave's own first match
-            const uint32_t nextv = __shfl_down(v, 1, 64);           // exclusive: what the lanes to the right found
-            carry[p2] = lane < 63 ? nextv : 0xFFFFu;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p2 = 0; p2 < 8; p2++) {
-            for (int w = wv + 1; w < GRID_THREADS / 64; w++) carry[p2] = min(carry[p2], (uint32_t)firstm[w * 8 + p2]);
-            if (carry[p2] == 0xFFFFu) carry[p2] = total;
-        }
-        const gptr<v4u> nxt4 = (gptr<v4u>)f.cell_nxt;
-        if (j1 == (int)total) {
-            // whoever owns the end of the stream also writes the sentinel row (several threads may: same values)
-            const uint32_t tt = total | (total << 16);
-            nxt4[total] = v4u{tt, tt, tt, tt};
-        }
-        for (int j = j1 - 1; j >= j0; j--) {
-            const int o = loct[j];
-#pragma unroll
-            for (int p2 = 0; p2 < 8; p2++)
-                if (o == p2 || o == p2 - 1) carry[p2] = (uint32_t)j;
-            nxt4[j] = v4u{carry[0] | (carry[1] << 16), carry[2] | (carry[3] << 16), carry[4] | (carry[5] << 16),
-                          carry[6] | (carry[7] << 16)};
-        }
+        const uint32_t c = (uint32_t)pos_in_grid(f, (int)k);                      // ix * 48 + iy: the cell the record sits in
+        const uint32_t cx = c / ORBM_GRID_ROWS, cy = c - cx * ORBM_GRID_ROWS;
+        ((gptr<v4f>)f.cell_rec)[i] = v4f{f.x[k], f.y[k], f.uright[k],
+                                         __uint_as_float(k | ((uint32_t)f.octave[k] << 16) | (cy << 20) | (cx << 26))};
     }
 }
 
@@ -492,8 +441,8 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
         o.cell_off = pk.add(nullptr, (ORBM_GRID_CELLS + 1) * 4);
         o.cell_idx = pk.add(nullptr, (n ? n : 1) * 4);
         o.cell_rec = pk.add(nullptr, (n ? n : 1) * 16);
-        o.has_nxt = v.n_levels <= 8 && v.n <= GRID_LDS_MAX_N;
-        o.cell_nxt = o.has_nxt ? pk.add(nullptr, (n + 1) * 16) : 0;
+        o.has_nxt = false;          // the skip lists of round 1 are gone: collect_kernel builds its own per-launch index
+        o.cell_nxt = 0;
         // room for a FeatureVector computed on the device later (orbm_frames_compute_bow): at most one node per feature
         o.fv_node = pk.add(v.fv_node, (size_t)v.n_nodes * 4, n * 4);
         o.fv_off = pk.add(v.fv_off, ((size_t)v.n_nodes + 1) * 4, (n + 1) * 4);

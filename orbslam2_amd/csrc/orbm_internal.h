@@ -20,7 +20,7 @@ struct FrameDev {
     const uint8_t *octave;
     uint8_t *mp_flags;
     uint32_t *cell_off, *cell_idx;
-    float4 *cell_rec;   // cell-ordered copy {x, y, uright, idx | octave << 16}: the window walk streams it
+    float4 *cell_rec;   // cell-ordered copy {x, y, uright, idx | octave << 16 | iy << 20 | ix << 26}: the window walk streams it
     // cell_nxt[j * 8 + p], j in [0, T] (T = cell_off[3072] keypoints are in the grid): first position j' >= j of the
     // cell-ordered stream whose octave is p - 1 or p (T if none): a walk that only accepts octaves {p-1, p} hops over the other records.  Null when n_levels > 8 or
     // n > 8192.

@@ -34,7 +34,7 @@ namespace {
 
 enum { MODE_LAST = 0, MODE_KF = 1, MODE_SIM3 = 2, MODE_INIT = 3, MODE_PROJ = 10 };
 
-constexpr int WIN_MAX_N = 8192;       // slot state lives in LDS: 5 x 4 B per keypoint
+constexpr int WIN_MAX_N = 8160;       // slot state lives in LDS: 5 x 4 B per keypoint (+ 256 B) within 160 KB
 constexpr uint32_t NOPOST = 0xFFFFFFFFu;
 
 struct WinParams {
@@ -61,8 +61,8 @@ struct FrameAccT {
 };
 
 // Frame::GetFeaturesInArea (Frame.cc:434-498) / KeyFrame::GetFeaturesInArea (KeyFrame.cc:766-812):
-// calls body(k, octave, uright) for every keypoint the reference would push, in the reference's order
-// (ix ascending, iy ascending, insertion order).  Cells (ix, minY..maxY) are consecutive in the CSR, so a
+// calls body(k, octave, uright, j) for every keypoint the reference would push, in the reference's order
+// (ix ascending, iy ascending, insertion order); j = its position in the cell-ordered stream.  Cells (ix, minY..maxY) are consecutive in the CSR, so a
 // column of the window is ONE contiguous run of 16-byte records.
 template <bool KF_MODE, typename Acc, typename Body>
 __device__ __forceinline__ void walk_window(const Acc &f, float x, float y, float r, int minLevel, int maxLevel,
@@ -83,13 +83,13 @@ __device__ __forceinline__ void walk_window(const Acc &f, float x, float y, floa
         for (uint32_t j = b; j < e; j++) {
             const v4f rc = f.rec[j];
             const uint32_t w = __float_as_uint(rc.w);
-            const int oct = (int)(w >> 16);
+            const int oct = (int)((w >> 16) & 15u);
             if (bCheckLevels) {
                 if (oct < minLevel) continue;
                 if (maxLevel >= 0 && oct > maxLevel) continue;
             }
             const float distx = __fsub_rn(rc.x, x), disty = __fsub_rn(rc.y, y);
-            if (fabsf(distx) < r && fabsf(disty) < r) body((int)(w & 0xFFFFu), oct, rc.z);
+            if (fabsf(distx) < r && fabsf(disty) < r) body((int)(w & 0xFFFFu), oct, rc.z, (int)j);
         }
     }
 }
@@ -181,41 +181,114 @@ __device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
     return MODE == MODE_PROJ || (MODE == MODE_LAST && S.QS.f3 != nullptr);
 }
 
-// ---- split form, kernel 1 of 2: ONE window walk per query, anywhere on the chip.  Nothing here depends on the slot
-// state, so queries are independent.  A workgroup stages the frame's grid and cell-ordered records in LDS once and
-// its waves then take rows of 64 queries (one per lane) with no barrier between them.  Per lane: a single flat loop
-// over the window's records (column changes are just another iteration, so a wave iterates max-over-lanes of the
-// window's size, not the sum over columns of the widest column run), branch-free gates, survivors parked in LDS;
-// then a second, wave-uniform loop computes the Hamming distances.  Each candidate that passes the static gates is
-// stored as k | oct << 16 | dist << 20 in reference visit order, in rows of 64 lanes (row i of a wave = candidate i
-// of its 64 queries; only rows some lane needs are written).
+// ---- split form, kernel 1 of 2: ONE window search per query, anywhere on the chip.  Nothing here depends on the slot
+// state, so queries are independent.  A workgroup first builds, in LDS, an index of the frame made for THIS launch's
+// windows: one structure per octave pair {p-1, p} (a query's level range is one such pair in a6, a5 and the Sim3 overload;
+// the overloads with wider ranges get ONE structure holding every octave), each with coarse columns of 2^k fine grid
+// columns (k chosen on the host from the launch's window radius: a window then spans at most ~4 coarse columns) and the 48
+// fine rows.  Records are bucketed by (coarse column, fine row): rows y0..y1 of one coarse column are ONE contiguous run of
+// 16-byte records, every one of which passes the level gate.  A query (one per lane) walks its few runs in a single flat
+// loop (a column change is just another iteration), parks the survivors of the exact gates of Frame::GetFeaturesInArea
+// (cell column inside [x0, x1], |dx| < r, |dy| < r; Frame.cc:434-498) and the stereo gate, then a second, wave-uniform
+// loop computes their Hamming distances.  The walk visits records in bucket order, not in the reference's visit order
+// (ix, iy, index in cell): the order is carried by the keys instead.  A candidate is the word
+//     dist << 17 | j << 4 | octave        j = the keypoint's position in the reference's cell-ordered stream (cell_idx)
+// so ascending words = ascending (distance, reference visit order): exactly the order in which the reference's strict-'<'
+// scan ranks its candidates.  Per query the EIGHT smallest words are kept, sorted: four in `head` (16 bytes, written for
+// every query), four in `tail` (written only when there are more than four).  Flags ride in the top bits of head[3]:
+// bit 31 = a tail exists, bit 30 = more than eight candidates (the claims kernel re-walks such a query if it is live),
+// bit 29 = more candidates than could be parked (their distances are unknown: always treated as live).
 constexpr int COLLECT_THREADS = 1024;
 constexpr int COST_CLASSES = 64;
+constexpr int PARK = 16;                    // survivors parked per query (LDS, u16 record positions)
+constexpr uint32_t W_INVALID = 0xFFFFFFFFu; // no candidate (bit 27 set; valid words stay below 2^27)
+constexpr uint32_t W_MORE = 1u << 31, W_INCOMPLETE = 1u << 30, W_UNKNOWN = 1u << 29, W_FLAGS = 7u << 29;
+
+struct CoarseCfg {
+    int nstruct;          // 8: one structure per octave pair {p-1, p}; 1: every octave in one structure
+    int kshift[8];        // coarse column = fine column >> kshift
+    int base[9];          // first bucket of structure s (bucket = base + coarse column * 48 + fine row); base[nstruct] = all buckets
+    int rec_cap;          // records the index may hold (2n with pairs, n otherwise)
+    int n_cap;            // keypoints per frame the launch was sized for
+};
+
+__device__ __forceinline__ uint32_t word_slot(uint32_t v) { return (v >> 4) & 0x1FFFu; }
+__device__ __forceinline__ int word_oct(uint32_t v) { return (int)(v & 15u); }
+__device__ __forceinline__ int word_dist(uint32_t v) { return (int)((v & ~W_FLAGS) >> 17); }
+__device__ __forceinline__ bool word_valid(uint32_t v) { return !(v & (1u << 27)); }
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  uint32_t *cand, uint32_t *cand_hi, uint8_t *ncand_out,
-                                                                  uint64_t *postable_out, int cap, int stage_nxt, int groups) {
+                                                                  v4u *head_out, v4u *tail_out, CoarseCfg cfg, int groups) {
     extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ int s_k[8], s_base[9];
+    __shared__ uint32_t s_part[COLLECT_THREADS / 64];
     const int inst = blockIdx.x / wgs_per_inst, part = blockIdx.x - inst * wgs_per_inst;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameG F(P.frames[P.frame_ids[inst]]);
-    const int n = F.n;
-    uint32_t *l_cell = lds;                                                      // 3076
-    v4f *l_rec = reinterpret_cast<v4f *>(lds + 3076);                            // 4n
-    // skip lists (orbm_internal.h, cell_nxt): staged when the frame has them and the launch left room
-    const bool have_nxt = stage_nxt && F.cell_nxt != nullptr;
-    uint16_t *l_nxt = reinterpret_cast<uint16_t *>(lds + 3076 + 4 * (size_t)n);  // (n + 1) x 8
-    uint16_t *l_cc = l_nxt + (stage_nxt ? 8 * ((size_t)n + 1) : 0);              // WIN_CACHE x COLLECT_THREADS stream positions
-    int *l_bucket = (int *)(l_cc + WIN_CACHE * COLLECT_THREADS);                 // cost classes
+    const int total = cfg.base[cfg.nstruct];                                     // buckets
+    const int offn = (total + 6) & ~1;                                           // u16 entries of c_off (see below), even
+    uint16_t *c_off = reinterpret_cast<uint16_t *>(lds);
+    v4f *c_rec = reinterpret_cast<v4f *>(lds + ((offn / 2 + 3) & ~3));
+    uint16_t *l_idx = reinterpret_cast<uint16_t *>(c_rec + cfg.rec_cap);          // stream position -> keypoint index
+    uint16_t *l_cc = l_idx + ((cfg.n_cap + 7) & ~7);                             // PARK x COLLECT_THREADS record positions
+    int *l_bucket = (int *)(l_cc + PARK * COLLECT_THREADS);                      // cost classes
     uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + COST_CLASSES);    // 2 x COLLECT_THREADS
-    for (int i = tid; i <= ORBM_GRID_CELLS; i += COLLECT_THREADS) l_cell[i] = F.cell_off[i];
-    for (int i = tid; i < n; i += COLLECT_THREADS) l_rec[i] = F.cell_rec[i];
-    if (have_nxt) {
-        const gptr<const v4u> g = (gptr<const v4u>)F.cell_nxt;
-        v4u *l = reinterpret_cast<v4u *>(l_nxt);
-        const int rows = (int)F.cell_off[ORBM_GRID_CELLS] + 1;
-        for (int i = tid; i < rows; i += COLLECT_THREADS) l[i] = g[i];
+    if (tid < 8) s_k[tid] = cfg.kshift[tid];
+    if (tid < 9) s_base[tid] = cfg.base[tid];
+    // ---- the index.  Bucket b's run is c_rec[c_off[b + 1] .. c_off[b + 2]): counters sit at c_off[b + 2] (two u16 per
+    // atomic word), are turned into start positions by an exclusive scan and advanced to END positions by the scatter.
+    uint32_t *cnt32 = lds;
+    for (int i = tid; i < offn / 2; i += COLLECT_THREADS) cnt32[i] = 0;
+    __syncthreads();
+    const int T = (int)F.cell_off[ORBM_GRID_CELLS];
+    const bool pairs = cfg.nstruct > 1;
+    auto bucket_add = [&](int b) {                                               // -> value of bucket b's u16 before the add
+        const uint32_t old = atomicAdd(&cnt32[(b + 2) >> 1], ((b + 2) & 1) ? 0x10000u : 1u);
+        return ((b + 2) & 1) ? old >> 16 : old & 0xFFFFu;
+    };
+    for (int j = tid; j < T; j += COLLECT_THREADS) {
+        const uint32_t w = __float_as_uint(F.cell_rec[j].w);
+        const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
+        l_idx[j] = (uint16_t)(w & 0xFFFFu);
+        if (pairs) {
+            if (oct <= 7) bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy);
+            if (oct + 1 <= 7) bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy);
+        } else {
+            bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy);
+        }
+    }
+    __syncthreads();
+    {
+        const int per = (total + COLLECT_THREADS - 1) / COLLECT_THREADS;
+        const int i0 = min(total, tid * per), i1 = min(total, i0 + per);
+        uint32_t sum = 0;
+        for (int i = i0; i < i1; i++) sum += c_off[i + 2];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w2 = 0; w2 < wave; w2++) run += s_part[w2];
+        for (int i = i0; i < i1; i++) { const uint32_t c = c_off[i + 2]; c_off[i + 2] = (uint16_t)run; run += c; }
+        if (tid == 0) { c_off[0] = 0; c_off[1] = 0; }
+    }
+    __syncthreads();
+    for (int j = tid; j < T; j += COLLECT_THREADS) {
+        const v4f rc = F.cell_rec[j];
+        const uint32_t w = __float_as_uint(rc.w);
+        const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
+        const v4f mine = {rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17))};
+        if (pairs) {
+            if (oct <= 7) c_rec[bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy)] = mine;
+            if (oct + 1 <= 7) c_rec[bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy)] = mine;
+        } else {
+            c_rec[bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy)] = mine;
+        }
     }
     __syncthreads();
     const QSrc S = query_source<MODE>(P, inst);
@@ -226,11 +299,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     // queries sorted together: `groups` rows of 64 per wave (2; 1 when the launch has few instances, so that one instance
     // spreads over more workgroups)
     const int SUPER = groups * COLLECT_THREADS;
-    const int lane = tid & 63, wave = tid >> 6;
-    // A wave costs what its widest window costs and window areas differ by more than 10x between pyramid levels, so
-    // the queries of a super-chunk are counting-sorted by the length of their walk (columns + records) and each
-    // wave takes one heavy and one light group of 64 (results are still written at the query's own position).
+    // A wave costs what its longest walk costs and window areas differ by more than 10x between pyramid levels, so
+    // the queries of a super-chunk are counting-sorted by window area (in cells) and each wave takes one heavy and one
+    // light group of 64 (results are written at the query's own position).
     const int n_super = (waves_per_inst * 64 + SUPER - 1) / SUPER;
+    const size_t qstride = (size_t)waves_per_inst * 64;
     for (int sc = part; sc < n_super; sc += wgs_per_inst) {
         if (tid < COST_CLASSES) l_bucket[tid] = 0;
         __syncthreads();
@@ -247,13 +320,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, t.r), inv_h)));
                 const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, t.r), inv_h)));
                 if (x1 >= x0 && y1 >= y0) {
-                    int recs = 0;                              // loop iterations of the walk: columns + records visited
-                    for (int ix = x0; ix <= x1; ix++)
-                        recs += (int)(l_cell[ix * ORBM_GRID_ROWS + y1 + 1] - l_cell[ix * ORBM_GRID_ROWS + y0]);
-                    const bool hop = have_nxt && (MODE == MODE_PROJ || MODE == MODE_SIM3 || MODE == MODE_INIT ||
-                                                  (t.maxL >= 0 && t.maxL <= 7 && t.maxL - t.minL <= 1));
-                    const int cnt = x1 - x0 + 1 + (hop ? recs / 3 : recs);
-                    c = cnt < 62 ? 1 + (cnt >> 1) : min(COST_CLASSES - 1, 32 + ((cnt - 62) >> 4));
+                    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+                    c = area < 124 ? 1 + (area >> 1) : min(COST_CLASSES - 1, 62 + ((area - 124) >> 6));
                 }
             }
             cls[h] = c;
@@ -271,7 +339,6 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
       for (int h = 0; h < groups; h++) {
         const int group = h == 0 ? wave : 2 * WAVES - 1 - wave;
         const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
-        const int rowi = qi >> 6;
         Query q = load_params<MODE>(P, F, S, qi);
         if (q.valid) load_desc<MODE>(S, qi, q);
         // Frame.cc:434-498 / KeyFrame.cc:766-812, as walk_window()
@@ -286,56 +353,42 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
         else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
         const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
-        // candidates 0..WIN_CACHE-1 of a query live in `cand`, the rest (up to cap) in `cand_hi`
-        uint32_t *row = cand + ((size_t)inst * waves_per_inst + rowi) * (WIN_CACHE * 64) + (qi & 63);
-        uint32_t *row_hi = cand_hi + ((size_t)inst * waves_per_inst + rowi) * ((size_t)(cap - WIN_CACHE) * 64) + (qi & 63);
-        // claimable candidates (distance <= the acceptance threshold): up to three slot ids, their count in bits 48-49,
-        // bit 50 = "treat as live" (more than three, or more candidates than a row holds)
-        uint64_t pw = 0;
-        int npost = 0;
-        int ncand = 0;      // candidates that passed the static gates
-        auto finish = [&](uint32_t v) {                         // v = k | oct << 16 -> adds the distance, notes claimables
-            const int k = (int)(v & 0xFFFFu);
-            const v4u dlo = gdesc[2 * k], dhi = gdesc[2 * k + 1];
-            const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
-            const uint32_t dist = hamming256(qd, cd);
-            if ((int)dist <= P.dist_th) {
-                if (npost < 3) pw |= (uint64_t)(uint32_t)k << (16 * npost);
-                npost++;
-            }
-            return v | (dist << 20);
-        };
-        // first phase: a single flat loop over the window's records (a column change is just another iteration);
-        // survivors are parked (LDS for the first WIN_CACHE, the row itself beyond) until the second phase
-        if (q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0) {
-            int ix = x0 - 1;
+        int ncand = 0;      // candidates that passed every gate
+        bool uncovered = false;
+        // first phase: a single flat loop over the runs of the window's coarse columns
+        if (q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0) {
+            // the structure of the octave pair {hi-1, hi} holds every octave of [lo, hi] when hi - lo <= 1; a wider (or
+            // open) range can only come with the one-structure index
+            int st = 0;
+            bool covered = !pairs;
+            if (pairs && hi <= 7 && hi >= 0 && hi - lo <= 1) { st = hi; covered = true; }
+            const int k = s_k[st], sb = s_base[st];
+            int X = (x0 >> k) - 1;
+            const int X1 = x1 >> k;
             uint32_t j = 0, e = 0;
-            bool more = true;
-            // octaves {hi-1, hi} cover [lo, hi] when hi - lo <= 1: hop along that pair's skip list (the gates below
-            // stay, the list only leaves out records that cannot pass the level gate)
-            const bool hop = have_nxt && hi <= 7 && hi - lo <= 1;
-            const uint16_t *nx = l_nxt + (hop ? hi : 0);
+            bool more = covered;
+            uncovered = !covered;                                // cannot happen with the launch rules below; if it does: re-walk
             while (more) {
                 if (j < e) {
                     const uint32_t jcur = j;
-                    const v4f rc = l_rec[j];
-                    j = hop ? (uint32_t)nx[(j + 1) * 8] : j + 1;
+                    const v4f rc = c_rec[j];
+                    j++;
                     const uint32_t w = __float_as_uint(rc.w);
-                    const int oct = (int)(w >> 16);
-                    int pass = (int)(oct >= lo) & (int)(oct <= hi) & (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
+                    const int oct = (int)((w >> 13) & 15u), cx = (int)(w >> 17);
+                    int pass = (int)(cx >= x0) & (int)(cx <= x1) & (int)(oct >= lo) & (int)(oct <= hi) &
+                               (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
                     if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
                     if (pass) {
-                        if (ncand < WIN_CACHE) l_cc[ncand * COLLECT_THREADS + tid] = (uint16_t)jcur;
-                        else if (ncand < cap) row_hi[(ncand - WIN_CACHE) * 64] = w;
+                        if (ncand < PARK) l_cc[ncand * COLLECT_THREADS + tid] = (uint16_t)jcur;
                         ncand++;
                     }
                 }
-                if (j >= e) {                                  // run finished (or empty): the next column, in the same iteration
-                    if (++ix > x1) more = false;
+                if (j >= e) {                                  // run finished (or empty): the next coarse column, in the same iteration
+                    if (++X > X1) more = false;
                     else {
-                        j = l_cell[ix * ORBM_GRID_ROWS + y0];
-                        e = l_cell[ix * ORBM_GRID_ROWS + y1 + 1];
-                        if (hop) j = nx[j * 8];
+                        const int b = sb + X * ORBM_GRID_ROWS;
+                        j = c_off[b + y0 + 1];
+                        e = c_off[b + y1 + 2];
                     }
                 }
                 // keeps this ONE loop: without a convergent operation here the compiler splits it into nested
@@ -343,22 +396,38 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // second phase: Hamming distances, wave-uniform trip counts
+        // second phase: Hamming distances, wave-uniform trip count; the eight smallest words, sorted
+        uint32_t k0 = W_INVALID, k1 = W_INVALID, k2 = W_INVALID, k3 = W_INVALID, k4 = W_INVALID, k5 = W_INVALID, k6 = W_INVALID, k7 = W_INVALID;
         {
-            int wn = min(ncand, cap);
+            int wn = min(ncand, PARK);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wn = max(wn, __shfl_xor(wn, off, 64));
             wn = __builtin_amdgcn_readfirstlane(wn);
-            for (int i = 0; i < min(wn, WIN_CACHE); i++)
-                if (i < ncand) row[i * 64] = finish(__float_as_uint(l_rec[l_cc[i * COLLECT_THREADS + tid]].w));
-            for (int i = WIN_CACHE; i < wn; i++)
-                if (i < ncand) row_hi[(i - WIN_CACHE) * 64] = finish(row_hi[(i - WIN_CACHE) * 64]);
+            for (int i = 0; i < wn; i++)
+                if (i < ncand) {
+                    const uint32_t w = __float_as_uint(c_rec[l_cc[i * COLLECT_THREADS + tid]].w);
+                    const uint32_t j13 = w & 0x1FFFu;
+                    const int kp = (int)l_idx[j13];
+                    const v4u dlo = gdesc[2 * kp], dhi = gdesc[2 * kp + 1];
+                    const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
+                    uint32_t x = (hamming256(qd, cd) << 17) | (j13 << 4) | ((w >> 13) & 15u), t;
+                    t = min(k0, x); x = max(k0, x); k0 = t;
+                    t = min(k1, x); x = max(k1, x); k1 = t;
+                    t = min(k2, x); x = max(k2, x); k2 = t;
+                    t = min(k3, x); x = max(k3, x); k3 = t;
+                    t = min(k4, x); x = max(k4, x); k4 = t;
+                    t = min(k5, x); x = max(k5, x); k5 = t;
+                    t = min(k6, x); x = max(k6, x); k6 = t;
+                    k7 = min(k7, x);
+                }
         }
-        pw |= (uint64_t)min(npost, 3) << 48;
-        if (npost > 3 || ncand > cap) pw |= 1ull << 50;
         if (qi < waves_per_inst * 64) {
-            ncand_out[(size_t)inst * waves_per_inst * 64 + qi] = (uint8_t)min(ncand, 255);
-            postable_out[(size_t)inst * waves_per_inst * 64 + qi] = pw;
+            if (ncand > 4) {
+                k3 |= W_MORE | (ncand > 8 ? W_INCOMPLETE : 0u) | (ncand > PARK ? W_UNKNOWN : 0u);
+                tail_out[(size_t)inst * qstride + qi] = v4u{k4, k5, k6, k7};
+            }
+            if (uncovered) k3 = W_FLAGS;                         // no candidate words, every flag: live, re-walked by the claims kernel
+            head_out[(size_t)inst * qstride + qi] = v4u{k0, k1, k2, k3};
         }
       }
         __syncthreads();     // l_perm and l_bucket are rewritten by the next super-chunk
@@ -368,8 +437,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 // ---- the claim loop.  PRE = false: collects inline (one kernel does everything; frame optionally staged in LDS).
 // PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
 template <int MODE, bool LDS_FRAME, bool PRE>
-__global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *cand, const uint8_t *ncand_in,
-                              const uint64_t *postable_in, int cap, const uint32_t *cand_hi) {
+__global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const v4u *tail_in) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameG F(P.frames[P.frame_ids[inst]]);
@@ -404,10 +472,14 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     const int Q = S.Q;
     int32_t *out = P.out + (size_t)inst * P.stride;
 
-    for (int i = tid; i < n; i += nthr) {
+    // Slots: the split form names a keypoint by its position j in the cell-ordered stream (that is what orders candidates
+    // of equal distance), the single-kernel forms by its index.
+    const int n_slots = PRE ? (int)F.cell_off[ORBM_GRID_CELLS] : n;
+    for (int i = tid; i < n_slots; i += nthr) {
         uint32_t s0;
+        const int kp = PRE ? (int)F.cell_idx[i] : i;
         if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
-        else s0 = P.slot_flags ? P.slot_flags[(size_t)inst * P.stride + i] : F.mp_flags[i];
+        else s0 = P.slot_flags ? P.slot_flags[(size_t)inst * P.stride + kp] : F.mp_flags[kp];
         state[i] = s0;
         owner[i] = -1;
         post0[i] = NOPOST; post1[i] = NOPOST;
@@ -423,15 +495,13 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
     const bool stereo_gate = has_stereo_gate<MODE>(S);
     const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
-    const uint8_t *nc_in = PRE ? ncand_in + (size_t)inst * waves_per_inst * 64 : nullptr;
-    const uint32_t *rows = PRE ? cand + (size_t)inst * waves_per_inst * (WIN_CACHE * 64) : nullptr;
-    const uint32_t *rows_hi = PRE ? cand_hi + (size_t)inst * waves_per_inst * ((size_t)(cap - WIN_CACHE) * 64) : nullptr;
+    const gptr<const v4u> heads = PRE ? (gptr<const v4u>)head_in + (size_t)inst * waves_per_inst * 64 : nullptr;
+    const gptr<const v4u> tails = PRE ? (gptr<const v4u>)tail_in + (size_t)inst * waves_per_inst * 64 : nullptr;
 
-    auto load_nc = [&](int qi) { return (PRE && qi < Q) ? (int)nc_in[qi] : 0; };
-    auto load_query = [&](int qi, int nc) {
+    auto load_query = [&](int qi, bool rewalk) {
         Query q = load_params<MODE>(P, F, S, qi);
         if (PRE) {
-            if (nc > cap) load_desc<MODE>(S, qi, q);           // only the re-walking fallback compares descriptors here
+            if (rewalk && q.valid) load_desc<MODE>(S, qi, q);  // only the re-walking fallback compares descriptors here
         } else if (q.valid) {
             load_desc<MODE>(S, qi, q);
         }
@@ -450,7 +520,9 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
 
     // One chunk of up to blockDim queries, one per lane, in ascending query index over tid (claim priority = tid).
     // Called by every thread of the workgroup (barriers inside).
-    auto process_chunk = [&](const int qi, const Query &cur, const int nc_pre, uint32_t (&cc)[WIN_CACHE]) {
+    // cc: the query's candidates as words dist << 17 | slot << 4 | octave (ascending = the reference's ranking); `complete`
+    // = cc holds every candidate (else the rounds walk the window again)
+    auto process_chunk = [&](const int qi, const Query &cur, const int nc_pre, const bool complete, uint32_t (&cc)[WIN_CACHE]) {
         bool unresolved = cur.valid;
         const uint32_t qd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
         const float x = cur.x, y = cur.y, r = cur.r, qangle = cur.angle;
@@ -465,12 +537,12 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         if (PRE) {
             ncand = nc_pre;
         } else if (unresolved) {
-            auto collect = [&](int k, int oct, float ur) {
+            auto collect = [&](int k, int oct, float ur, int) {
                 if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                 if (ncand < WIN_CACHE) {
                     const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                     const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t v = (uint32_t)k | ((uint32_t)oct << 16) | (hamming256(qd, cd) << 20);
+                    const uint32_t v = ((uint32_t)k << 4) | (uint32_t)oct | (hamming256(qd, cd) << 17);
 #pragma unroll
                     for (int i = 0; i < WIN_CACHE; i++) if (i == ncand) cc[i] = v;
                 }
@@ -480,15 +552,10 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             else walk_window<false>(acc, x, y, r, minL, maxL, collect);
         }
         if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
-        // candidate i of this lane's query: the first WIN_CACHE in registers, the rest (split form, rows of `cap`
-        // entries) re-read from the row; i is wave-uniform
-        const bool cached = ncand <= cap;
-        const int wave_ncand = wave_max(min(ncand, cap));
-        const uint32_t *myrow_hi = PRE ? rows_hi + (size_t)(qi >> 6) * ((size_t)(cap - WIN_CACHE) * 64) + (qi & 63) : nullptr;
-        auto cand_at = [&](int i) -> uint32_t {
-            if (i < WIN_CACHE) return cc[i];
-            return (PRE && i < ncand) ? myrow_hi[(i - WIN_CACHE) * 64] : 0u;
-        };
+        // candidate i of this lane's query (registers; i is wave-uniform)
+        const bool cached = PRE ? complete : ncand <= WIN_CACHE;
+        const int wave_ncand = wave_max(min(ncand, WIN_CACHE));
+        auto cand_at = [&](int i) -> uint32_t { return cc[i]; };
 
         // A query none of whose claimable candidates (distance <= threshold) is still free can never be accepted, and
         // blocked slots stay blocked, so it is settled without taking part in the rounds; a chunk with no live query
@@ -497,11 +564,11 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             bool live = false;
             for (int i = 0; i < wave_ncand; i++) {
                 const uint32_t v = cand_at(i);
-                if (i < ncand && (int)(v >> 20) <= thr) {
-                    const uint32_t st = state[v & 0xFFFFu];
+                if (i < ncand && word_dist(v) <= thr) {
+                    const uint32_t st = state[word_slot(v)];
                     bool blocked;
                     if (MODE == MODE_PROJ || MODE == MODE_LAST) blocked = (st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS);
-                    else if (MODE == MODE_INIT) blocked = (int)st <= (int)(v >> 20);
+                    else if (MODE == MODE_INIT) blocked = (int)st <= word_dist(v);
                     else blocked = (st & ORBM_MP_PRESENT) != 0;
                     if (!blocked) live = true;
                 }
@@ -542,14 +609,14 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                     // wave-uniform trip count: the register array is indexed by a scalar (v_movrels), no unrolling
                     for (int i = 0; i < wave_ncand; i++) {
                         const uint32_t v = cand_at(i);
-                        if (i < ncand) consider((int)(v & 0xFFFFu), (int)((v >> 16) & 15u), (int)(v >> 20));
+                        if (i < ncand) consider((int)word_slot(v), word_oct(v), word_dist(v));
                     }
                 } else {
-                    auto body = [&](int k, int oct, float ur) {
+                    auto body = [&](int k, int oct, float ur, int j) {
                         if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                         const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                         const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        consider(k, oct, (int)hamming256(qd, cd));
+                        consider(PRE ? j : k, oct, (int)hamming256(qd, cd));
                     };
                     if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, body);
                     else walk_window<false>(acc, x, y, r, minL, maxL, body);
@@ -577,19 +644,20 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                         for (int i = 0; i < wave_ncand; i++) {
                             const uint32_t v = cand_at(i);
                             if (i < ncand) {
-                                const int k = (int)(v & 0xFFFFu);
-                                if (!is_blocked(state[k], (int)(v >> 20))) atomicMin(&post[k], (uint32_t)tid);
+                                const int k = (int)word_slot(v);
+                                if (!is_blocked(state[k], word_dist(v))) atomicMin(&post[k], (uint32_t)tid);
                             }
                         }
                     } else {
-                        auto body = [&](int k, int oct, float ur) {
+                        auto body = [&](int k, int oct, float ur, int j) {
                             if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
+                            const int slot = PRE ? j : k;
                             if (MODE == MODE_INIT) {
                                 const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                                 const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                                if (is_blocked(state[k], (int)hamming256(qd, cd))) return;
-                            } else if (is_blocked(state[k], 0)) return;
-                            atomicMin(&post[k], (uint32_t)tid);
+                                if (is_blocked(state[slot], (int)hamming256(qd, cd))) return;
+                            } else if (is_blocked(state[slot], 0)) return;
+                            atomicMin(&post[slot], (uint32_t)tid);
                         };
                         if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, body);
                         else walk_window<false>(acc, x, y, r, minL, maxL, body);
@@ -620,10 +688,11 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                     else
                         accept = bestDist <= thr;                                         // :1904 / :2062 / :533
                     if (accept) {
+                        const int bestKp = PRE ? (int)F.cell_idx[bestIdx] : bestIdx;      // the slot's keypoint
                         if (MODE == MODE_INIT) {
                             const int old = owner[bestIdx];
                             if (old >= 0) { out[old] = -1; my_matches--; }                 // :629-633
-                            out[qi] = bestIdx; owner[bestIdx] = qi; state[bestIdx] = (uint32_t)bestDist;  // :636-638
+                            out[qi] = bestKp; owner[bestIdx] = qi; state[bestIdx] = (uint32_t)bestDist;  // :636-638
                         } else {
                             uint32_t ns = ORBM_MP_PRESENT;
                             if ((MODE != MODE_PROJ && MODE != MODE_LAST) || (qflags & ORBM_Q_OBS)) ns |= ORBM_MP_OBS;
@@ -632,7 +701,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                         }
                         my_matches++;
                         if (use_hist) {
-                            const int bin = rot_bin(qangle, F.angle[bestIdx]);             // :644-651 / :1911-1918 / :2079-2090
+                            const int bin = rot_bin(qangle, F.angle[bestKp]);              // :644-651 / :1911-1918 / :2079-2090
                             atomicAdd(&hist[bin], 1);
                             if (MODE != MODE_INIT) atomicOr(&binmask[bestIdx], 1u << bin);
                         }
@@ -640,14 +709,14 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
                 }
             }
             // the other post buffer is idle in this phase (decide only reads `post`): clear it for the next round
-            for (int i = tid; i < n; i += nthr) post_next[i] = NOPOST;
+            for (int i = tid; i < n_slots; i += nthr) post_next[i] = NOPOST;
             if (!__syncthreads_or(unresolved ? 1 : 0)) break;
             round++;
         }
         // leave both post buffers clean for the next chunk
         {
             uint32_t *post = (round & 1) ? post1 : post0;
-            for (int i = tid; i < n; i += nthr) post[i] = NOPOST;
+            for (int i = tid; i < n_slots; i += nthr) post[i] = NOPOST;
         }
         __syncthreads();
 
@@ -655,19 +724,19 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
 
     if (!PRE) {
         // single-kernel form: queries in index order, the NEXT chunk's query is loaded while the current one is matched
-        Query nextq = load_query(tid, 0);
+        Query nextq = load_query(tid, false);
         for (int base_q = 0; base_q < Q; base_q += nthr) {
             const int qi = base_q + tid;
             const Query cur = nextq;
-            nextq = load_query(qi + nthr, 0);
+            nextq = load_query(qi + nthr, false);
             uint32_t cc[WIN_CACHE];
 #pragma unroll
             for (int i = 0; i < WIN_CACHE; i++) cc[i] = 0;
-            process_chunk(qi, cur, 0, cc);
+            process_chunk(qi, cur, 0, true, cc);
         }
     } else {
-        // split form.  collect_kernel left one word per query naming its claimable candidates (distance <= threshold).
-        // A query none of whose claimable candidates is still free can never be accepted, and blocked slots stay
+        // split form.  collect_kernel left every query's smallest candidate words (head: four, 16 bytes).  A query none
+        // of whose claimable candidates (distance <= threshold) is still free can never be accepted, and blocked slots stay
         // blocked, so the queries are first scanned SCAN_U x blockDim at a time against the current slot state (a few
         // instructions each, loads independent) and only the live ones, compacted in index order, go through the
         // rounds.  Typical inputs leave a few percent of the queries live.
@@ -675,22 +744,22 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
         int *cnts = hist + 64 + SCAN_U * nthr / 2;                          // SCAN_U x waves (+1)
         int *pre = cnts + SCAN_U * 16 + 1;
         const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
-        const uint64_t *pw = postable_in + (size_t)inst * waves_per_inst * 64;
         for (int sb = 0; sb < Q; sb += SCAN_U * nthr) {
-            uint64_t w[SCAN_U];
+            v4u w[SCAN_U];
 #pragma unroll
             for (int u = 0; u < SCAN_U; u++) {
                 const int qi = sb + u * nthr + tid;
-                w[u] = qi < Q ? pw[qi] : 0ull;
+                w[u] = qi < Q ? heads[qi] : v4u{W_INVALID, W_INVALID, W_INVALID, W_INVALID};
             }
             uint32_t lm = 0, ranks = 0, rankhi = 0;
 #pragma unroll
             for (int u = 0; u < SCAN_U; u++) {
-                bool live = (w[u] >> 50) & 1ull;
-                const int c = (int)((w[u] >> 48) & 3ull);
+                const uint32_t hw[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                // words ascend: if the fourth is claimable and a tail exists, the tail may hold claimable ones too
+                bool live = word_valid(hw[3]) && ((hw[3] & W_UNKNOWN) || ((hw[3] & W_MORE) && word_dist(hw[3]) <= thr));
 #pragma unroll
-                for (int j = 0; j < 3; j++)
-                    if (j < c && !is_blocked(state[(uint32_t)(w[u] >> (16 * j)) & 0xFFFFu], 0)) live = true;
+                for (int j = 0; j < 4; j++)
+                    if (word_valid(hw[j]) && word_dist(hw[j]) <= thr && !is_blocked(state[word_slot(hw[j])], word_dist(hw[j]))) live = true;
                 const uint64_t m = __ballot(live);
                 if (lane == 0) cnts[u * NW + wave] = __popcll(m);
                 const uint32_t rk = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -715,13 +784,25 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             for (int c0 = 0; c0 < nlive; c0 += nthr) {
                 const int li = c0 + tid;
                 const int qi = li < nlive ? sb + (int)qlist[li] : Q;
-                const int nc = load_nc(qi);
-                const Query cur = load_query(qi, nc);
                 uint32_t cc[WIN_CACHE];
-                const uint32_t *row = rows + (size_t)(qi >> 6) * (WIN_CACHE * 64) + (qi & 63);
 #pragma unroll
-                for (int i = 0; i < WIN_CACHE; i++) cc[i] = i < min(nc, WIN_CACHE) ? row[i * 64] : 0u;
-                process_chunk(qi, cur, nc, cc);
+                for (int i = 0; i < WIN_CACHE; i++) cc[i] = W_INVALID;
+                bool complete = true;
+                int nc = 0;
+                if (qi < Q) {
+                    const v4u h4 = heads[qi];
+                    cc[0] = h4.x; cc[1] = h4.y; cc[2] = h4.z; cc[3] = h4.w;
+                    if (word_valid(h4.w)) {
+                        complete = !(h4.w & (W_INCOMPLETE | W_UNKNOWN));
+                        if (h4.w & W_MORE) { const v4u t4 = tails[qi]; cc[4] = t4.x; cc[5] = t4.y; cc[6] = t4.z; cc[7] = t4.w; }
+                        cc[3] = h4.w & ~W_FLAGS;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) nc += word_valid(cc[i]) ? 1 : 0;
+                    if (!complete) nc = WIN_CACHE + 1;                      // more candidates than words: the rounds walk the window
+                }
+                const Query cur = load_query(qi, !complete);
+                process_chunk(qi, cur, nc, complete, cc);
             }
         }
     }
@@ -757,7 +838,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             }
             if (removed) atomicSub(nmatch, removed);
         } else {
-            for (int i = tid; i < n; i += nthr)
+            for (int i = tid; i < n_slots; i += nthr)
                 if (binmask[i] & ~keepmask) owner[i] = -2;                                 // slot set to NULL (:1942 / :2115)
         }
         __syncthreads();
@@ -767,6 +848,11 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const uint32_t *c
             const int m = out[i];
             if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
         }
+    } else if (PRE) {
+        // keypoints outside the grid (no stream position) are never candidates: -1
+        for (int i = tid; i < n; i += nthr) out[i] = -1;
+        __syncthreads();
+        for (int i = tid; i < n_slots; i += nthr) out[F.cell_idx[i]] = owner[i];
     } else {
         for (int i = tid; i < n; i += nthr) out[i] = owner[i];
     }
@@ -795,7 +881,7 @@ __global__ __launch_bounds__(256) void free_kernel(WinParams P, int chunks_per_i
         const v4u d0 = p4[0], d1 = p4[1];
         const uint32_t qd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         int bestDist = INT_MAX, bestIdx = -1;
-        auto body = [&](int k, int oct, float kur) {
+        auto body = [&](int k, int oct, float kur, int) {
             if (oct < minL || oct > maxL) return;                                          // :1207 / :1406 / :1608
             if (chi2_gate) {
                 const float inv = __fdiv_rn(1.0f, F.sigma2[oct]);
@@ -824,21 +910,48 @@ constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B de
 
 template <int MODE, bool LDS_FRAME, bool PRE>
 int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
-                  const uint32_t *cand, const uint8_t *ncand, const uint64_t *postable, int cap,
-                  const uint32_t *cand_hi = nullptr) {
+                  const v4u *head, const v4u *tail) {
     const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
                         (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
+    if (lds > 160 * 1024)
+        return orbm_fail(ctx, ORBM_ELIMIT, "windowed search: frames of %d keypoints need %zu bytes of LDS slot state (limit 163840)", max_n, lds);
     HIPCHK(ctx, (orbm_allow_dynamic_lds<&window_kernel<MODE, LDS_FRAME, PRE>>(ctx, lds)));
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
-                       waves_per_inst, cand, ncand, postable, cap, cand_hi);
+                       waves_per_inst, head, tail);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
 
-// dynamic LDS of collect_kernel: grid, records, optional skip lists, parking (u16), cost classes, lane assignment (u16)
-static size_t collect_lds_bytes(int max_n, bool with_nxt) {
-    return (3076 + 4 * (size_t)max_n) * 4 + (with_nxt ? 16 * ((size_t)max_n + 1) : 0) + (size_t)WIN_CACHE * COLLECT_THREADS * 2 +
-           COST_CLASSES * 4 + 2 * COLLECT_THREADS * 2 + 64;
+// The index collect_kernel builds in LDS (see there): structures, coarse-column shifts, bucket bases.  `pairs`: one
+// structure per octave pair; rmax_px[p] = the largest window half-size expected at level p (efficiency only: a window
+// of any size is walked correctly, it just spans more coarse columns).
+static CoarseCfg coarse_cfg(bool pairs, const float *rmax_px, int max_n) {
+    CoarseCfg c;
+    memset(&c, 0, sizeof c);
+    c.nstruct = pairs ? 8 : 1;
+    int b = 0;
+    for (int s2 = 0; s2 < c.nstruct; s2++) {
+        // fine columns spanned: 2r/10 + 2..3; aim at no more than ~4 coarse columns per window
+        const float need = (2.0f * rmax_px[s2] / 10.0f + 2.0f) / 3.0f;
+        int k = 0;
+        while ((1 << k) < need && k < 3) k++;
+        c.kshift[s2] = k;
+        c.base[s2] = b;
+        b += (ORBM_GRID_COLS >> k) * ORBM_GRID_ROWS;
+    }
+    for (int s2 = c.nstruct; s2 <= 8; s2++) c.base[s2] = b;
+    c.rec_cap = (pairs ? 2 : 1) * max_n + 4;
+    c.n_cap = max_n;
+    return c;
+}
+
+// dynamic LDS of collect_kernel: bucket offsets (u16), index records, stream position -> keypoint (u16), parking (u16),
+// cost classes, lane assignment (u16)
+static size_t collect_lds_bytes(const CoarseCfg &c) {
+    const int total = c.base[c.nstruct];
+    const size_t offn = (size_t)((total + 6) & ~1);
+    return (((offn / 2 + 3) & ~(size_t)3)) * 4 + (size_t)c.rec_cap * 16 + (size_t)((c.n_cap + 7) & ~7) * 2 +
+           (size_t)PARK * COLLECT_THREADS * 2 + COST_CLASSES * 4 + 2 * COLLECT_THREADS * 2 + 64;
 }
 
 // tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
@@ -846,55 +959,58 @@ static size_t collect_lds_bytes(int max_n, bool with_nxt) {
 int g_win_variant = 0;
 
 template <int MODE>
-int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q) {
-    // frames too large for collect_kernel's LDS staging use the single-kernel form
-    const bool single = g_win_variant != 0 ||
-                        collect_lds_bytes(max_n, false) > 160 * 1024;
+int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q, int max_levels) {
+    // window half-sizes this launch will see, per level (nominal 1.2 pyramid; only steers the coarse-column width)
+    float rmax[8];
+    float sf = 1.0f;
+    for (int l = 0; l < 8; l++, sf *= 1.2f) {
+        if (MODE == MODE_PROJ) rmax[l] = 4.0f * (P.th != 1.0f ? P.th : 1.0f) * sf;
+        else if (MODE == MODE_INIT) rmax[l] = (float)P.window;
+        else rmax[l] = 10.0f * sf;
+    }
+    // a6, a5 and the Sim3 overload ask for one octave pair per query; the other two overloads for wider or open ranges
+    constexpr bool PAIRS = MODE == MODE_PROJ || MODE == MODE_INIT || MODE == MODE_SIM3;
+    if (!PAIRS) rmax[0] = 20.0f;
+    const CoarseCfg cfg = coarse_cfg(PAIRS, rmax, max_n);
+    // frames too large for collect_kernel's LDS index (or with more than 8 pyramid levels) use the single-kernel form
+    const bool single = g_win_variant != 0 || collect_lds_bytes(cfg) > 160 * 1024 || max_n > 8191 || (PAIRS && max_levels > 8);
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
-            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr, nullptr, WIN_CACHE);
-        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, nullptr, WIN_CACHE);
+            return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr);
+        return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr);
     }
     {
         const int waves_per_inst = (max_q + 63) / 64;
-        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr, nullptr, WIN_CACHE);
+        if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr);
         const size_t rows = (size_t)n_inst * waves_per_inst;
-        // candidates kept per query: 64 unless the batch is so large that the rows would not fit 8 GB (queries with
-        // more candidates than that are still exact: the claims kernel re-walks their window)
-        int cap = 64;
-        while (cap > WIN_CACHE && rows * cap * 256 > ((size_t)8 << 30)) cap >>= 1;
-        const size_t cand_bytes = rows * cap * 64 * 4;
-        int rc = orbm_ws2_reserve(ctx, cand_bytes + rows * 64 * 9 + 256);
+        // per query: 16 bytes of head (always written) + 16 bytes of tail (written when a query has more than 4 candidates)
+        int rc = orbm_ws2_reserve(ctx, rows * 64 * 32 + 256);
         if (rc) return rc;
-        uint32_t *cand = (uint32_t *)ctx->ws2;                                   // rows x WIN_CACHE x 64
-        uint32_t *cand_hi = cand + rows * WIN_CACHE * 64;                        // rows x (cap - WIN_CACHE) x 64
-        uint64_t *postable = (uint64_t *)((char *)ctx->ws2 + cand_bytes);
-        uint8_t *ncand = (uint8_t *)ctx->ws2 + cand_bytes + rows * 64 * 8;
-        // enough workgroups to fill the chip, each with enough rows to pay for staging the frame
+        v4u *head = (v4u *)ctx->ws2, *tail = head + rows * 64;
+        // enough workgroups to fill the chip, each with enough rows to pay for building the index
         constexpr int WAVES = COLLECT_THREADS / 64;
         int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
         // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
         const int groups = (long long)n_inst * wgs_per_inst < 256 ? 1 : 2;
         if (groups == 1) wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
-        const int stage_nxt = collect_lds_bytes(max_n, true) <= 160 * 1024;
-        const size_t lds = collect_lds_bytes(max_n, stage_nxt != 0);
+        const size_t lds = collect_lds_bytes(cfg);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, cand, cand_hi, ncand, postable, cap, stage_nxt, groups);
+                           waves_per_inst, wgs_per_inst, head, tail, cfg, groups);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
-        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, cand, ncand, postable, cap, cand_hi);
+        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail);
     }
     return ORBM_OK;
 }
 
-int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n, int max_q) {
+int launch_window(orbm_ctx *ctx, int mode, const WinParams &P, int n_inst, int max_n, int max_q, int max_levels) {
     switch (mode) {
-        case MODE_LAST: return launch_mode<MODE_LAST>(ctx, P, n_inst, max_n, max_q);
-        case MODE_KF: return launch_mode<MODE_KF>(ctx, P, n_inst, max_n, max_q);
-        case MODE_SIM3: return launch_mode<MODE_SIM3>(ctx, P, n_inst, max_n, max_q);
-        case MODE_INIT: return launch_mode<MODE_INIT>(ctx, P, n_inst, max_n, max_q);
-        default: return launch_mode<MODE_PROJ>(ctx, P, n_inst, max_n, max_q);
+        case MODE_LAST: return launch_mode<MODE_LAST>(ctx, P, n_inst, max_n, max_q, max_levels);
+        case MODE_KF: return launch_mode<MODE_KF>(ctx, P, n_inst, max_n, max_q, max_levels);
+        case MODE_SIM3: return launch_mode<MODE_SIM3>(ctx, P, n_inst, max_n, max_q, max_levels);
+        case MODE_INIT: return launch_mode<MODE_INIT>(ctx, P, n_inst, max_n, max_q, max_levels);
+        default: return launch_mode<MODE_PROJ>(ctx, P, n_inst, max_n, max_q, max_levels);
     }
 }
 
@@ -906,13 +1022,14 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
         return orbm_fail(ctx, ORBM_EINVAL, "%s: null argument or negative size", who);
     if (n_inst == 0) return ORBM_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int max_n = 0, max_q = 0;
+    int max_n = 0, max_q = 0, max_levels = 0;
     if (!io_on_device) {
         int rc = orbm_check_frames(ctx, n_inst, frame, "frame");
         if (!rc) rc = orbm_check_qsets(ctx, n_inst, qset, mode == MODE_PROJ ? 0 : 1, "qset");
         if (rc) return rc;
         for (int k = 0; k < n_inst; k++) {
             max_n = std::max(max_n, ctx->h_frames[frame[k]].n);
+            max_levels = std::max(max_levels, ctx->h_frames[frame[k]].n_levels);
             max_q = std::max(max_q, ctx->h_qsets[qset[k]].n);
         }
         if (max_n > stride) return orbm_fail(ctx, ORBM_EINVAL, "%s: stride %d < largest frame %d", who, stride, max_n);
@@ -921,6 +1038,11 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
         // the ids live on the device: bound the query count by the largest live query set of the context
         for (size_t k = 0; k < ctx->h_qsets.size(); k++)
             if (ctx->qset_arena[k] >= 0) max_q = std::max(max_q, ctx->h_qsets[k].n);
+        // ... the keypoints (LDS sizing) and the pyramid depth by the live frames of the context
+        int live_n = 0;
+        for (size_t k = 0; k < ctx->h_frames.size(); k++)
+            if (ctx->frame_arena[k] >= 0) { live_n = std::max(live_n, ctx->h_frames[k].n); max_levels = std::max(max_levels, ctx->h_frames[k].n_levels); }
+        max_n = std::min(max_n, live_n);
     }
     if (max_n > WIN_MAX_N)
         return orbm_fail(ctx, ORBM_ELIMIT, "%s: frames of more than %d keypoints are not supported by the windowed kernels (got %d)", who, WIN_MAX_N, max_n);
@@ -944,7 +1066,7 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
     P.slot_flags = (const uint8_t *)dsf;
     P.out = (int32_t *)down; P.counts = (int32_t *)dc;
     P.th = th; P.ratio = ratio; P.dist_th = dist_th; P.check_ori = check_ori; P.stride = stride;
-    rc = launch_window(ctx, mode, P, n_inst, std::max(max_n, 1), max_q);
+    rc = launch_window(ctx, mode, P, n_inst, std::max(max_n, 1), max_q, max_levels);
     if (rc) return rc;
     return io.finish();
 }
@@ -996,7 +1118,7 @@ extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, f
     P.frame_ids = d_ids; P.qset_ids = d_ids + 1;
     P.prev_xy = d_prev; P.out = d_m12; P.counts = d_count;
     P.th = 1.0f; P.ratio = ratio; P.dist_th = ORBM_TH_LOW; P.check_ori = check_ori; P.stride = n1; P.window = window;
-    rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1), n1);
+    rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1), n1, ctx->h_frames[frame2].n_levels);
     if (rc) return rc;
     int32_t count = 0;
     HIPCHK(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));

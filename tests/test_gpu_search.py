@@ -610,34 +610,34 @@ def test_bow_fuzz_near_thresholds(ctx, orc, form):
 
 def test_all_pairs_end_to_end_on_one_gpu(ctx, orc):
     """BASELINE config 5 in small: every keyframe pair of a resident store through allpairs.all_pairs (device index lists,
-    device outputs, fixed-stride records), one rank; every record against the oracle."""
+    compact records left on the device by orbm_allpairs_batch), one rank; every record against the oracle."""
     import torch
     from orbslam2_amd import allpairs
-    n_kf, n = 20, 500
+    n_kf, n, threshold = 20, 500, 15
     kfs = synth.keyframe_pool(seed=synth.SEED0 + 5, n_kf=n_kf, n=n, window=int(n / 0.6))
     ids = ctx.upload_frames(kfs)
     dev = torch.device("cuda:0")
     tid = torch.tensor(ids, device=dev, dtype=torch.int32)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    batch = 64
-
-    def match_fn(ta, tb):
-        fa = tid[ta.long()].contiguous(); fb = tid[tb.long()].contiguous()
-        match = torch.empty((batch, n), dtype=torch.int32, device=dev); counts = torch.empty(batch, dtype=torch.int32, device=dev)
-        ctx.search_bow_dev(1, batch, fa.data_ptr(), fb.data_ptr(), 0.75, True, n, match.data_ptr(), counts.data_ptr())
-        return counts, match
-
     try:
-        res = allpairs.all_pairs(torch, None, n_kf, stride=n, batch=batch, match_fn=match_fn, device=dev, tile=8)
+        fn = allpairs.device_batch_fn(torch, ctx, tid, 1, 0.75, 50, True, n, threshold, list_cap=64 * n, comm_device=dev)
+        res = allpairs.all_pairs(torch, None, n_kf, batch=64, threshold=threshold, batch_fn=fn, tile=8, comm_device=dev)
     finally:
         ctx.use_own_stream()
     assert len(res) == n_kf * (n_kf - 1) // 2
-    tot = 0
-    for (a, b), (cnt, row) in res.items():
+    counts = res.counts()
+    tot = n_listed = 0
+    for (a, b), cnt in counts.items():
         wc, wm, _ = orc.search_bow(1, kfs[a], kfs[b], 0.75, True)
-        assert cnt == wc and np.array_equal(row, wm), (a, b)
+        assert cnt == wc, (a, b)
+        row = res.match_row(a, b, n)
+        if wc >= threshold:
+            assert np.array_equal(row, wm), (a, b)
+            n_listed += 1
+        else:
+            assert row is None
         tot += wc
-    assert tot > 2000
+    assert tot > 2000 and n_listed > 10
     ctx.free_frames(ids)
 
 
