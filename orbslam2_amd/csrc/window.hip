@@ -25,6 +25,7 @@
 // the best / second-best pair of a final query is the one the sequential loop would have found; the lowest
 // unresolved query is always final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
@@ -142,7 +143,9 @@ __device__ __forceinline__ Query load_params(const WinParams &P, const FrameG &F
             q.x = QS.f0[qi]; q.y = QS.f1[qi];
             if (MODE == MODE_PROJ) {
                 const int lvl = QS.l0[qi];
-                float rv = ((double)QS.f3[qi] > 0.998) ? 2.5f : 4.0f;              // :168-174
+                // :168-174 compares the float viewCos with the double 0.998: true exactly for floats >= 0.998f (0x3F7F7CEE,
+                // whose value lies above 0.998; the float below it lies below)
+                float rv = (QS.f3[qi] >= 0.998f) ? 2.5f : 4.0f;
                 if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                          // :61, :84-85
                 q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
                 q.minL = lvl - 1; q.maxL = lvl;
@@ -155,6 +158,20 @@ __device__ __forceinline__ Query load_params(const WinParams &P, const FrameG &F
         }
     }
     return q;
+}
+
+// window half-size of query qi (the same arithmetic as load_params), < 0 for a query that does not search
+template <int MODE>
+__device__ __forceinline__ float load_radius(const WinParams &P, const FrameG &F, const QSrc &S, int qi) {
+    if (qi >= S.Q) return -1.f;
+    if (MODE == MODE_INIT) return S.F1.octave[qi] == 0 ? (float)P.window : -1.f;
+    if (!(S.QS.flags[qi] & ORBM_Q_VALID)) return -1.f;
+    if (MODE == MODE_PROJ) {
+        float rv = (S.QS.f3[qi] >= 0.998f) ? 2.5f : 4.0f;
+        if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);
+        return __fmul_rn(rv, F.sf[S.QS.l0[qi]]);
+    }
+    return S.QS.f2[qi];
 }
 
 template <int MODE>
@@ -194,15 +211,18 @@ __device__ __forceinline__ bool has_stereo_gate(const QSrc &S) {
 // (ix, iy, index in cell): the order is carried by the keys instead.  A candidate is the word
 //     dist << 17 | j << 4 | octave        j = the keypoint's position in the reference's cell-ordered stream (cell_idx)
 // so ascending words = ascending (distance, reference visit order): exactly the order in which the reference's strict-'<'
-// scan ranks its candidates.  Per query the EIGHT smallest words are kept, sorted: four in `head` (16 bytes, written for
-// every query), four in `tail` (written only when there are more than four).  Flags ride in the top bits of head[3]:
-// bit 31 = a tail exists, bit 30 = more than eight candidates (the claims kernel re-walks such a query if it is live),
-// bit 29 = more candidates than could be parked (their distances are unknown: always treated as live).
+// scan ranks its candidates, so the claims kernel can take them in any order.  Per query the FOUR smallest words go, sorted,
+// into `head` (16 bytes, written for every query: the claims kernel's liveness scan reads nothing else); up to `tcap` more
+// go, unsorted, into `tail` (4-byte stores, only for queries with more than four candidates).  Bits 28-31 of head[3] and
+// head[2] = number of tail words (8 bits); 255 = more candidates than the tail holds (their distances are unknown: such a
+// query counts as live and the claims kernel walks its window again).  Survivors are parked in LDS (the first PARK) and
+// in the query's own tail slots (the rest) between the two phases.
 constexpr int COLLECT_THREADS = 1024;
 constexpr int COST_CLASSES = 64;
-constexpr int PARK = 16;                    // survivors parked per query (LDS, u16 record positions)
+constexpr int PARK = 16;                    // survivors parked per query in LDS (u16 record positions); = WIN_CACHE
 constexpr uint32_t W_INVALID = 0xFFFFFFFFu; // no candidate (bit 27 set; valid words stay below 2^27)
-constexpr uint32_t W_MORE = 1u << 31, W_INCOMPLETE = 1u << 30, W_UNKNOWN = 1u << 29, W_FLAGS = 7u << 29;
+constexpr uint32_t W_FLAGS = 15u << 28;     // bits 28-31 of head[2] and head[3] carry the tail count
+constexpr int TAIL_UNKNOWN = 255;           // tail count: more candidates than the tail holds
 
 struct CoarseCfg {
     int nstruct;          // 8: one structure per octave pair {p-1, p}; 1: every octave in one structure
@@ -216,10 +236,13 @@ __device__ __forceinline__ uint32_t word_slot(uint32_t v) { return (v >> 4) & 0x
 __device__ __forceinline__ int word_oct(uint32_t v) { return (int)(v & 15u); }
 __device__ __forceinline__ int word_dist(uint32_t v) { return (int)((v & ~W_FLAGS) >> 17); }
 __device__ __forceinline__ bool word_valid(uint32_t v) { return !(v & (1u << 27)); }
+__device__ __forceinline__ int word_tail(uint32_t head2, uint32_t head3) {
+    return word_valid(head3) ? (int)((head3 >> 28) | ((head2 >> 28) << 4)) : 0;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  v4u *head_out, v4u *tail_out, CoarseCfg cfg, int groups) {
+                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[COLLECT_THREADS / 64];
@@ -311,29 +334,32 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (h >= groups) { cls[h] = 0; rank[h] = 0; continue; }
-            const Query t = load_params<MODE>(P, F, S, sc * SUPER + h * COLLECT_THREADS + tid);
+            // cost class = the window's area in cells, from its half-size alone (no window arithmetic here)
+            const float rr = load_radius<MODE>(P, F, S, sc * SUPER + h * COLLECT_THREADS + tid);
             int c = 0;
-            if (t.valid) {
-                const float xr = __fsub_rn(t.x, min_x), yr = __fsub_rn(t.y, min_y);
-                const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, t.r), inv_w)));
-                const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, t.r), inv_w)));
-                const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, t.r), inv_h)));
-                const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, t.r), inv_h)));
-                if (x1 >= x0 && y1 >= y0) {
-                    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-                    c = area < 124 ? 1 + (area >> 1) : min(COST_CLASSES - 1, 62 + ((area - 124) >> 6));
-                }
+            if (rr >= 0.f) {
+                const int area = (int)((2.f * rr * inv_w + 2.f) * (2.f * rr * inv_h + 2.f));
+                c = area < 124 ? 1 + (max(area, 0) >> 1) : min(COST_CLASSES - 1, 62 + ((area - 124) >> 6));
             }
             cls[h] = c;
             rank[h] = atomicAdd(&l_bucket[c], 1);
         }
         __syncthreads();
+        if (wave == 0) {                                          // class c starts after every heavier class: suffix sums, once
+            const int mine = l_bucket[lane];
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int dn = __shfl_down(incl, d, 64);
+                if (lane + d < 64) incl += dn;
+            }
+            l_bucket[lane] = incl - mine;
+        }
+        __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (h >= groups) continue;
-            int start = 0;
-            for (int bk = COST_CLASSES - 1; bk > cls[h]; bk--) start += l_bucket[bk];
-            l_perm[start + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
+            l_perm[l_bucket[cls[h]] + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
         }
         __syncthreads();
       for (int h = 0; h < groups; h++) {
@@ -355,6 +381,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
         int ncand = 0;      // candidates that passed every gate
         bool uncovered = false;
+        uint32_t *mytail = tail_out + ((size_t)inst * qstride + min(qi, (int)qstride - 1)) * tcap;
         // first phase: a single flat loop over the runs of the window's coarse columns
         if (q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0) {
             // the structure of the octave pair {hi-1, hi} holds every octave of [lo, hi] when hi - lo <= 1; a wider (or
@@ -380,6 +407,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                     if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
                     if (pass) {
                         if (ncand < PARK) l_cc[ncand * COLLECT_THREADS + tid] = (uint16_t)jcur;
+                        else if (ncand < tcap + 4) mytail[ncand - 4] = jcur;   // parked where its word will go
                         ncand++;
                     }
                 }
@@ -396,16 +424,18 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // second phase: Hamming distances, wave-uniform trip count; the eight smallest words, sorted
-        uint32_t k0 = W_INVALID, k1 = W_INVALID, k2 = W_INVALID, k3 = W_INVALID, k4 = W_INVALID, k5 = W_INVALID, k6 = W_INVALID, k7 = W_INVALID;
+        // second phase: Hamming distances, wave-uniform trip count; the four smallest words sorted, the others to the tail
+        uint32_t k0 = W_INVALID, k1 = W_INVALID, k2 = W_INVALID, k3 = W_INVALID;
         {
-            int wn = min(ncand, PARK);
+            const int nhave = min(ncand, tcap + 4);
+            int wn = nhave;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wn = max(wn, __shfl_xor(wn, off, 64));
             wn = __builtin_amdgcn_readfirstlane(wn);
             for (int i = 0; i < wn; i++)
-                if (i < ncand) {
-                    const uint32_t w = __float_as_uint(c_rec[l_cc[i * COLLECT_THREADS + tid]].w);
+                if (i < nhave) {
+                    const uint32_t pos = i < PARK ? (uint32_t)l_cc[i * COLLECT_THREADS + tid] : mytail[i - 4];
+                    const uint32_t w = __float_as_uint(c_rec[pos].w);
                     const uint32_t j13 = w & 0x1FFFu;
                     const int kp = (int)l_idx[j13];
                     const v4u dlo = gdesc[2 * kp], dhi = gdesc[2 * kp + 1];
@@ -415,18 +445,15 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                     t = min(k1, x); x = max(k1, x); k1 = t;
                     t = min(k2, x); x = max(k2, x); k2 = t;
                     t = min(k3, x); x = max(k3, x); k3 = t;
-                    t = min(k4, x); x = max(k4, x); k4 = t;
-                    t = min(k5, x); x = max(k5, x); k5 = t;
-                    t = min(k6, x); x = max(k6, x); k6 = t;
-                    k7 = min(k7, x);
+                    if (i >= 4) mytail[i - 4] = x;               // what fell out of the four (a real word from the fifth candidate on)
                 }
         }
         if (qi < waves_per_inst * 64) {
             if (ncand > 4) {
-                k3 |= W_MORE | (ncand > 8 ? W_INCOMPLETE : 0u) | (ncand > PARK ? W_UNKNOWN : 0u);
-                tail_out[(size_t)inst * qstride + qi] = v4u{k4, k5, k6, k7};
+                const uint32_t tc = ncand > tcap + 4 ? (uint32_t)TAIL_UNKNOWN : (uint32_t)(ncand - 4);
+                k3 |= (tc & 15u) << 28; k2 |= (tc >> 4) << 28;
             }
-            if (uncovered) k3 = W_FLAGS;                         // no candidate words, every flag: live, re-walked by the claims kernel
+            if (uncovered) { k2 = W_FLAGS; k3 = W_FLAGS; }       // no candidate words, count 255: live, re-walked by the claims kernel
             head_out[(size_t)inst * qstride + qi] = v4u{k0, k1, k2, k3};
         }
       }
@@ -437,7 +464,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 // ---- the claim loop.  PRE = false: collects inline (one kernel does everything; frame optionally staged in LDS).
 // PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
 template <int MODE, bool LDS_FRAME, bool PRE>
-__global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const v4u *tail_in) {
+__global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const uint32_t *tail_in, int tcap) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int inst = blockIdx.x;
     const FrameG F(P.frames[P.frame_ids[inst]]);
@@ -472,12 +499,12 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     const int Q = S.Q;
     int32_t *out = P.out + (size_t)inst * P.stride;
 
-    // Slots: the split form names a keypoint by its position j in the cell-ordered stream (that is what orders candidates
-    // of equal distance), the single-kernel forms by its index.
-    const int n_slots = PRE ? (int)F.cell_off[ORBM_GRID_CELLS] : n;
+    // Slots: a keypoint is named by its position j in the cell-ordered stream: that is what ranks candidates of equal
+    // distance (the reference's visit order), so candidate words order themselves.
+    const int n_slots = (int)F.cell_off[ORBM_GRID_CELLS];
     for (int i = tid; i < n_slots; i += nthr) {
         uint32_t s0;
-        const int kp = PRE ? (int)F.cell_idx[i] : i;
+        const int kp = (int)F.cell_idx[i];
         if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
         else s0 = P.slot_flags ? P.slot_flags[(size_t)inst * P.stride + kp] : F.mp_flags[kp];
         state[i] = s0;
@@ -496,7 +523,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
     int my_matches = 0;
     const gptr<const v4u> heads = PRE ? (gptr<const v4u>)head_in + (size_t)inst * waves_per_inst * 64 : nullptr;
-    const gptr<const v4u> tails = PRE ? (gptr<const v4u>)tail_in + (size_t)inst * waves_per_inst * 64 : nullptr;
+    const gptr<const uint32_t> tails = PRE ? in_global(tail_in) + (size_t)inst * waves_per_inst * 64 * tcap : nullptr;
 
     auto load_query = [&](int qi, bool rewalk) {
         Query q = load_params<MODE>(P, F, S, qi);
@@ -537,12 +564,12 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
         if (PRE) {
             ncand = nc_pre;
         } else if (unresolved) {
-            auto collect = [&](int k, int oct, float ur, int) {
+            auto collect = [&](int k, int oct, float ur, int j) {
                 if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                 if (ncand < WIN_CACHE) {
                     const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                     const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    const uint32_t v = ((uint32_t)k << 4) | (uint32_t)oct | (hamming256(qd, cd) << 17);
+                    const uint32_t v = ((uint32_t)j << 4) | (uint32_t)oct | (hamming256(qd, cd) << 17);
 #pragma unroll
                     for (int i = 0; i < WIN_CACHE; i++) if (i == ncand) cc[i] = v;
                 }
@@ -552,10 +579,15 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             else walk_window<false>(acc, x, y, r, minL, maxL, collect);
         }
         if (ncand == 0) unresolved = false;   // empty window: nothing to match, nothing to claim (:91-92)
-        // candidate i of this lane's query (registers; i is wave-uniform)
+        // candidate i of this lane's query: the first WIN_CACHE in registers, the rest (split form) re-read from the
+        // query's tail; i is wave-uniform
         const bool cached = PRE ? complete : ncand <= WIN_CACHE;
-        const int wave_ncand = wave_max(min(ncand, WIN_CACHE));
-        auto cand_at = [&](int i) -> uint32_t { return cc[i]; };
+        const int wave_ncand = wave_max(cached ? ncand : 0);
+        const gptr<const uint32_t> mytail = PRE ? tails + (size_t)min(qi, max(Q - 1, 0)) * tcap : nullptr;
+        auto cand_at = [&](int i) -> uint32_t {
+            if (i < WIN_CACHE) return cc[i];
+            return (PRE && i < ncand) ? mytail[i - 4] : W_INVALID;
+        };
 
         // A query none of whose claimable candidates (distance <= threshold) is still free can never be accepted, and
         // blocked slots stay blocked, so it is settled without taking part in the rounds; a chunk with no live query
@@ -581,10 +613,12 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
         while (true) {
             uint32_t *post = (round & 1) ? post1 : post0;
             uint32_t *post_next = (round & 1) ? post0 : post1;
-            int bestDist = MODE == MODE_INIT ? INT_MAX : 256, bestDist2 = bestDist, bestIdx = -1, bestIdx2 = -1;
-            int bestLevel = -1, bestLevel2 = -1;
-            // the reference's inner loop body for one candidate that passed the static gates
-            auto consider = [&](int k, int oct, int dist) {
+            // The reference's inner loop body for one candidate that passed the static gates.  Its strict-'<' best /
+            // second-best scan in visit order ends with the two smallest (distance, visit position) pairs = the two smallest
+            // words, whatever order they are offered in.
+            uint32_t bestW = W_INVALID, secondW = W_INVALID;
+            auto consider = [&](uint32_t w) {
+                const int k = (int)word_slot(w), dist = word_dist(w);
                 const uint32_t st = state[k];
                 if (MODE == MODE_PROJ || MODE == MODE_LAST) {
                     if ((st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS)) return;              // :113-115 / :1879-1881
@@ -593,15 +627,8 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                 }
                 if (MODE == MODE_INIT) { if ((int)st <= dist) return; }                    // :608
                 if (dist <= thr) atomicMin(&post[k], (uint32_t)tid);                       // this query may still claim k
-                // strict '<' on the best, else strict '<' on the second (:124-137 etc.), as selects: with branches the
-                // compiler keeps the two indices in a scratch-memory array and stores through a computed offset
-                const bool b1 = dist < bestDist, b2 = !b1 && dist < bestDist2;
-                bestDist2 = b1 ? bestDist : (b2 ? dist : bestDist2);
-                bestLevel2 = b1 ? bestLevel : (b2 ? oct : bestLevel2);
-                bestIdx2 = b1 ? bestIdx : (b2 ? k : bestIdx2);
-                bestDist = b1 ? dist : bestDist;
-                bestLevel = b1 ? oct : bestLevel;
-                bestIdx = b1 ? k : bestIdx;
+                secondW = min(max(bestW, w), secondW);                                     // :124-137 etc.
+                bestW = min(bestW, w);
             };
             // ---- evaluate ---------------------------------------------------------------------------
             if (unresolved) {
@@ -609,19 +636,24 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                     // wave-uniform trip count: the register array is indexed by a scalar (v_movrels), no unrolling
                     for (int i = 0; i < wave_ncand; i++) {
                         const uint32_t v = cand_at(i);
-                        if (i < ncand) consider((int)word_slot(v), word_oct(v), word_dist(v));
+                        if (i < ncand) consider(v);
                     }
                 } else {
                     auto body = [&](int k, int oct, float ur, int j) {
                         if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
                         const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                         const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        consider(PRE ? j : k, oct, (int)hamming256(qd, cd));
+                        consider((hamming256(qd, cd) << 17) | ((uint32_t)j << 4) | (uint32_t)oct);
                     };
                     if (MODE == MODE_SIM3) walk_window<true>(acc, x, y, r, minL, maxL, body);
                     else walk_window<false>(acc, x, y, r, minL, maxL, body);
                 }
             }
+            const int none = MODE == MODE_INIT ? INT_MAX : 256;                            // :594-595 / :100-103 etc.
+            const bool has1 = word_valid(bestW), has2 = word_valid(secondW);
+            const int bestDist = has1 ? word_dist(bestW) : none, bestDist2 = has2 ? word_dist(secondW) : none;
+            const int bestIdx = has1 ? (int)word_slot(bestW) : -1, bestIdx2 = has2 ? (int)word_slot(secondW) : -1;
+            const int bestLevel = has1 ? word_oct(bestW) : -1, bestLevel2 = has2 ? word_oct(secondW) : -1;
             // a query that can still be accepted also names its second-best free slot where a ratio test reads it: lower
             // queries' interest in a slot must be visible to whoever wants to take it (claimable slots are posted above)
             constexpr bool USES_SECOND = MODE == MODE_PROJ || MODE == MODE_INIT;
@@ -651,7 +683,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                     } else {
                         auto body = [&](int k, int oct, float ur, int j) {
                             if (!static_gates<MODE>(cur, stereo_gate, oct, ur)) return;
-                            const int slot = PRE ? j : k;
+                            const int slot = j;
                             if (MODE == MODE_INIT) {
                                 const v4u lo = acc.desc[2 * k], hi = acc.desc[2 * k + 1];
                                 const uint32_t cd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -688,7 +720,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                     else
                         accept = bestDist <= thr;                                         // :1904 / :2062 / :533
                     if (accept) {
-                        const int bestKp = PRE ? (int)F.cell_idx[bestIdx] : bestIdx;      // the slot's keypoint
+                        const int bestKp = (int)F.cell_idx[bestIdx];                      // the slot's keypoint
                         if (MODE == MODE_INIT) {
                             const int old = owner[bestIdx];
                             if (old >= 0) { out[old] = -1; my_matches--; }                 // :629-633
@@ -756,7 +788,8 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             for (int u = 0; u < SCAN_U; u++) {
                 const uint32_t hw[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
                 // words ascend: if the fourth is claimable and a tail exists, the tail may hold claimable ones too
-                bool live = word_valid(hw[3]) && ((hw[3] & W_UNKNOWN) || ((hw[3] & W_MORE) && word_dist(hw[3]) <= thr));
+                const int tc = word_tail(hw[2], hw[3]);
+                bool live = tc == TAIL_UNKNOWN || (tc > 0 && word_dist(hw[3]) <= thr);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (word_valid(hw[j]) && word_dist(hw[j]) <= thr && !is_blocked(state[word_slot(hw[j])], word_dist(hw[j]))) live = true;
@@ -792,14 +825,24 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                 if (qi < Q) {
                     const v4u h4 = heads[qi];
                     cc[0] = h4.x; cc[1] = h4.y; cc[2] = h4.z; cc[3] = h4.w;
-                    if (word_valid(h4.w)) {
-                        complete = !(h4.w & (W_INCOMPLETE | W_UNKNOWN));
-                        if (h4.w & W_MORE) { const v4u t4 = tails[qi]; cc[4] = t4.x; cc[5] = t4.y; cc[6] = t4.z; cc[7] = t4.w; }
-                        cc[3] = h4.w & ~W_FLAGS;
+                    const int tc = word_tail(h4.z, h4.w);
+                    if (word_valid(h4.w)) { cc[2] = h4.z & ~W_FLAGS; cc[3] = h4.w & ~W_FLAGS; }
+                    complete = tc != TAIL_UNKNOWN;
+                    if (complete && tc > 0) {
+                        const gptr<const v4u> tq = (gptr<const v4u>)(tails + (size_t)qi * tcap);   // tcap is a multiple of 4
+#pragma unroll
+                        for (int g = 0; g < (WIN_CACHE - 4) / 4; g++)
+                            if (tc > 4 * g) {
+                                const v4u t4 = tq[g];
+                                cc[4 + 4 * g] = t4.x;
+                                cc[5 + 4 * g] = tc > 4 * g + 1 ? t4.y : W_INVALID;
+                                cc[6 + 4 * g] = tc > 4 * g + 2 ? t4.z : W_INVALID;
+                                cc[7 + 4 * g] = tc > 4 * g + 3 ? t4.w : W_INVALID;
+                            }
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; i++) nc += word_valid(cc[i]) ? 1 : 0;
-                    if (!complete) nc = WIN_CACHE + 1;                      // more candidates than words: the rounds walk the window
+                    for (int i = 0; i < 4; i++) nc += word_valid(cc[i]) ? 1 : 0;
+                    nc = complete ? nc + tc : tcap + 5;                     // more candidates than words: the rounds walk the window
                 }
                 const Query cur = load_query(qi, !complete);
                 process_chunk(qi, cur, nc, complete, cc);
@@ -848,13 +891,11 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             const int m = out[i];
             if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
         }
-    } else if (PRE) {
+    } else {
         // keypoints outside the grid (no stream position) are never candidates: -1
         for (int i = tid; i < n; i += nthr) out[i] = -1;
         __syncthreads();
         for (int i = tid; i < n_slots; i += nthr) out[F.cell_idx[i]] = owner[i];
-    } else {
-        for (int i = tid; i < n; i += nthr) out[i] = owner[i];
     }
     if (tid == 0) P.counts[inst] = *nmatch;
 }
@@ -910,14 +951,14 @@ constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B de
 
 template <int MODE, bool LDS_FRAME, bool PRE>
 int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
-                  const v4u *head, const v4u *tail) {
+                  const v4u *head, const uint32_t *tail, int tcap = 0) {
     const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
                         (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
     if (lds > 160 * 1024)
         return orbm_fail(ctx, ORBM_ELIMIT, "windowed search: frames of %d keypoints need %zu bytes of LDS slot state (limit 163840)", max_n, lds);
     HIPCHK(ctx, (orbm_allow_dynamic_lds<&window_kernel<MODE, LDS_FRAME, PRE>>(ctx, lds)));
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
-                       waves_per_inst, head, tail);
+                       waves_per_inst, head, tail, tcap);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
@@ -983,23 +1024,31 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         const int waves_per_inst = (max_q + 63) / 64;
         if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr);
         const size_t rows = (size_t)n_inst * waves_per_inst;
-        // per query: 16 bytes of head (always written) + 16 bytes of tail (written when a query has more than 4 candidates)
-        int rc = orbm_ws2_reserve(ctx, rows * 64 * 32 + 256);
+        // per query: 16 bytes of head (always written) + room for tcap tail words (written for queries with more than 4
+        // candidates): 60 unless the batch is so large that this would not fit 8 GB (queries with more candidates than that
+        // are still exact: the claims kernel walks their window again)
+        int tcap = 60;
+        while (tcap > 12 && rows * 64 * (16 + 4 * (size_t)tcap) > ((size_t)8 << 30)) tcap = tcap / 2 & ~3;
+        int rc = orbm_ws2_reserve(ctx, rows * 64 * (16 + 4 * (size_t)tcap) + 256);
         if (rc) return rc;
-        v4u *head = (v4u *)ctx->ws2, *tail = head + rows * 64;
+        v4u *head = (v4u *)ctx->ws2;
+        uint32_t *tail = (uint32_t *)(head + rows * 64);
         // enough workgroups to fill the chip, each with enough rows to pay for building the index
         constexpr int WAVES = COLLECT_THREADS / 64;
-        int wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
+        // one workgroup per CU is enough (the LDS index allows no second one) and every workgroup builds the index once
+        static const int wg_target_env = [] { const char *e = getenv("ORBM_WIN_WGS"); return e ? atoi(e) : 0; }();
+        const int wg_target = wg_target_env > 0 ? wg_target_env : std::max(64, ctx->prop.multiProcessorCount);
+        int wgs_per_inst = std::max(1, std::min((wg_target + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
         // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
-        const int groups = (long long)n_inst * wgs_per_inst < 256 ? 1 : 2;
-        if (groups == 1) wgs_per_inst = std::max(1, std::min((2048 + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
+        const int groups = (long long)n_inst * wgs_per_inst < wg_target ? 1 : 2;
+        if (groups == 1) wgs_per_inst = std::max(1, std::min((wg_target + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
         const size_t lds = collect_lds_bytes(cfg);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, head, tail, cfg, groups);
+                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
-        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail);
+        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail, tcap);
     }
     return ORBM_OK;
 }

@@ -25,7 +25,8 @@ tfr = torch.tensor(np.resize(fid, n_inst), device=dev); tqs = torch.tensor(np.re
 owner = torch.empty((n_inst, 2000), dtype=torch.int32, device=dev); cnt = torch.empty(n_inst, dtype=torch.int32, device=dev)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 bytes_inst = 50000 * (32 + 20 + 1) + 2000 * 49 + 3073 * 4 + 2000 * 4
-for th in (1.0, 3.0, 5.0, 8.0):
+THS = [float(t) for t in os.environ.get("ORBM_TH", "1,3,5,8").split(",")]
+for th in THS:
     ts = []
     for rep in range(4):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
