@@ -30,7 +30,17 @@ KeyFrameDatabase::KeyFrameDatabase(const ORBVocabulary &voc) : mpVoc(&voc) {
     mvInvertedFile.resize(voc.size());
 }
 
-KeyFrameDatabase::~KeyFrameDatabase() {}   // device copies go with the thread's context
+KeyFrameDatabase::~KeyFrameDatabase() {
+    if (mCtx) orbm_destroy(static_cast<orbm_ctx *>(mCtx));   // frees every device BowVector with it
+}
+
+// The database is shared between threads (add / erase from LocalMapping, DetectLoopCandidates from LoopClosing,
+// DetectRelocalizationCandidates from Tracking: LocalMapping.cc:ProcessNewKeyFrame, LoopClosing.cc:DetectLoop,
+// Tracking.cc:1738), so its device BowVectors live in a context of its own, used only under mMutex.
+static orbm_ctx *DbCtx(void *&slot) {
+    if (!slot) slot = detail::NewCtx();
+    return static_cast<orbm_ctx *>(slot);
+}
 
 void KeyFrameDatabase::add(KeyFrame *pKF) {
     unique_lock<mutex> lock(mMutex);
@@ -38,7 +48,8 @@ void KeyFrameDatabase::add(KeyFrame *pKF) {
     if (!mDeviceBow.count(pKF)) {
         FlatBow fb(pKF->mBowVec);
         int32_t id = -1;
-        detail::HostCheck(orbm_bowvecs_upload(detail::HostCtx(), 1, &fb.view, &id), "orbm_bowvecs_upload");
+        orbm_ctx *ctx = DbCtx(mCtx);
+        detail::CheckOn(ctx, orbm_bowvecs_upload(ctx, 1, &fb.view, &id), "orbm_bowvecs_upload");
         mDeviceBow[pKF] = id;
     }
 }
@@ -56,27 +67,32 @@ void KeyFrameDatabase::erase(KeyFrame *pKF) {
     auto it = mDeviceBow.find(pKF);
     if (it != mDeviceBow.end()) {
         int32_t id = it->second;
-        detail::HostCheck(orbm_bowvecs_free(detail::HostCtx(), 1, &id), "orbm_bowvecs_free");
+        orbm_ctx *ctx = DbCtx(mCtx);
+        detail::CheckOn(ctx, orbm_bowvecs_free(ctx, 1, &id), "orbm_bowvecs_free");
         mDeviceBow.erase(it);
     }
 }
 
 void KeyFrameDatabase::clear() {
+    unique_lock<mutex> lock(mMutex);
     mvInvertedFile.clear();
     mvInvertedFile.resize(mpVoc->size());
     vector<int32_t> ids;
     for (auto &kv : mDeviceBow) ids.push_back(kv.second);
-    if (!ids.empty()) detail::HostCheck(orbm_bowvecs_free(detail::HostCtx(), (int)ids.size(), ids.data()), "orbm_bowvecs_free");
+    if (!ids.empty()) {
+        orbm_ctx *ctx = DbCtx(mCtx);
+        detail::CheckOn(ctx, orbm_bowvecs_free(ctx, (int)ids.size(), ids.data()), "orbm_bowvecs_free");
+    }
     mDeviceBow.clear();
 }
 
 vector<float> KeyFrameDatabase::ScoreAgainst(const DBoW2::BowVector &query, const vector<KeyFrame *> &kfs) {
     vector<float> out(kfs.size());
     if (kfs.empty()) return out;
-    orbm_ctx *ctx = detail::HostCtx();
+    orbm_ctx *ctx = DbCtx(mCtx);          // the callers hold mMutex
     FlatBow fq(query);
     int32_t qid = -1;
-    detail::HostCheck(orbm_bowvecs_upload(ctx, 1, &fq.view, &qid), "orbm_bowvecs_upload");
+    detail::CheckOn(ctx, orbm_bowvecs_upload(ctx, 1, &fq.view, &qid), "orbm_bowvecs_upload");
     vector<int32_t> a(kfs.size(), qid), b(kfs.size());
     for (size_t i = 0; i < kfs.size(); i++) {
         auto it = mDeviceBow.find(kfs[i]);
@@ -86,7 +102,7 @@ vector<float> KeyFrameDatabase::ScoreAgainst(const DBoW2::BowVector &query, cons
     vector<double> score(kfs.size());
     const int rc = orbm_bow_score_batch(ctx, (int)kfs.size(), a.data(), b.data(), score.data(), nullptr, 0);
     orbm_bowvecs_free(ctx, 1, &qid);
-    detail::HostCheck(rc, "orbm_bow_score_batch");
+    detail::CheckOn(ctx, rc, "orbm_bow_score_batch");
     for (size_t i = 0; i < kfs.size(); i++) out[i] = (float)score[i];      // float si = mpVoc->score(...)
     return out;
 }

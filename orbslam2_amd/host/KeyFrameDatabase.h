@@ -2,9 +2,9 @@
 // methods.  The inverted file and the list logic are the reference's (pointer work, kept on the host in its order);
 // the `mpVoc->score(...)` loop over the keyframes that share enough words (KeyFrameDataBase.cc:179-196, 347-361) is
 // ONE batched call on the GPU (orbm_bow_score_batch): each keyframe's BowVector is uploaded once, at add().
-// All calls must come from one thread (the device copies live in that thread's context); the reference calls
-// add/erase from LocalMapping and Detect* from LoopClosing / Tracking under a mutex -- route them through one thread
-// or give the database its own thread.
+// The reference calls add/erase from LocalMapping and Detect* from LoopClosing / Tracking; so does this class: the
+// device BowVectors live in a GPU context owned by the database (created at the first add), every use of it is under
+// mMutex, and the destructor releases it.
 #pragma once
 #include <list>
 #include <map>
@@ -38,6 +38,7 @@ protected:
     std::vector<std::list<KeyFrame *>> mvInvertedFile;
     std::map<KeyFrame *, int> mDeviceBow;   // keyframe -> device BowVector id
     std::mutex mMutex;
+    void *mCtx = nullptr;                   // orbm_ctx of this database (not a thread's): see the header comment
 };
 
 }  // namespace ORB_SLAM2

@@ -3,11 +3,15 @@
 // context the methods throw (there is no CPU fallback).
 #include "ORBmatcher.h"
 
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <list>
+#include <map>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 
 #include "../../include/orbmatch.h"
 #include "host_ctx.h"
@@ -21,35 +25,60 @@ const int ORBmatcher::TH_HIGH = 100;      // ORBmatcher.cc:37
 const int ORBmatcher::TH_LOW = 50;        // ORBmatcher.cc:38
 const int ORBmatcher::HISTO_LENGTH = 30;  // ORBmatcher.cc:39
 
-float Frame::fx, Frame::fy, Frame::cx, Frame::cy;
-float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
-float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+// Frame's static members (Frame.cc:32-34) belong to the host project's Frame.cc; a stand-alone build that uses
+// orbslam_types.h defines them in its own translation unit (tests/cpp/test_orbmatcher.cc does).
 
 namespace {
-int g_device = -1;
+std::atomic<int> g_device{-1};
 }
 
 // ---- one C-ABI context per calling thread (the reference calls the matcher from three threads) -------------
+// The context also owns the thread's RESIDENCY table: device copies of the Frames / KeyFrames this thread has searched,
+// kept between calls (BASELINE north star: "descriptor storage, the grid-cell index and the FeatureVector grouping
+// change to device-resident layouts").  Keys are (kind, mnId, descriptor buffer, N) + a content fingerprint, never the
+// object's address, so a recycled Frame object (Tracking's mCurrentFrame) or a freed KeyFrame cannot alias.
 namespace detail {
 namespace {
+struct ResKey {
+    bool kf; long unsigned int id; const void *desc; int n;
+    bool operator<(const ResKey &o) const { return std::tie(kf, id, desc, n) < std::tie(o.kf, o.id, o.desc, o.n); }
+};
+struct ResEntry {
+    int32_t frame = -1;
+    uint64_t print = 0;          // fingerprint of sampled descriptor rows and keypoints
+    size_t fv_size = 0;          // FeatureVector nodes the device copy was built from (0: none yet)
+    vector<uint8_t> flags;       // mp_flags as last sent
+    std::list<ResKey>::iterator lru;
+};
 struct ThreadCtx {
     orbm_ctx *ctx = nullptr;
-    ~ThreadCtx() { if (ctx) orbm_destroy(ctx); }
+    std::map<ResKey, ResEntry> resident;
+    std::list<ResKey> lru[2];    // [0] Frames, [1] KeyFrames; front = most recent
+    int hold = 0;                // > 0 while a batched call collects handles: nothing is dropped until it ends
+    ~ThreadCtx() { if (ctx) orbm_destroy(ctx); }   // frees every device copy with it
 };
-}  // namespace
-orbm_ctx *HostCtx() {
+ThreadCtx &Thread() {
     static thread_local ThreadCtx t;
-    if (!t.ctx) {
-        int dev = g_device;
-        if (dev < 0) { const char *e = getenv("ORBMATCH_DEVICE"); dev = e ? atoi(e) : 0; }
-        t.ctx = orbm_create(dev);
-        if (!t.ctx) throw runtime_error(string("ORBmatcher: cannot create a GPU context: ") + orbm_last_error(nullptr));
-    }
+    return t;
+}
+std::atomic<size_t> g_limit_kf{16384}, g_limit_frames{8};
+}  // namespace
+orbm_ctx *NewCtx() {
+    int dev = g_device;
+    if (dev < 0) { const char *e = getenv("ORBMATCH_DEVICE"); dev = e ? atoi(e) : 0; }
+    orbm_ctx *c = orbm_create(dev);
+    if (!c) throw runtime_error(string("ORBmatcher: cannot create a GPU context: ") + orbm_last_error(nullptr));
+    return c;
+}
+orbm_ctx *HostCtx() {
+    ThreadCtx &t = Thread();
+    if (!t.ctx) t.ctx = NewCtx();
     return t.ctx;
 }
-void HostCheck(int rc, const char *what) {
-    if (rc < 0) throw runtime_error(string("ORBmatcher: ") + what + " failed: " + orbm_last_error(HostCtx()));
+void CheckOn(orbm_ctx *ctx, int rc, const char *what) {
+    if (rc < 0) throw runtime_error(string("ORBmatcher: ") + what + " failed: " + orbm_last_error(ctx));
 }
+void HostCheck(int rc, const char *what) { CheckOn(HostCtx(), rc, what); }
 }  // namespace detail
 
 namespace {
@@ -115,17 +144,88 @@ void Flatten(Flat &o, KeyFrame *pKF, bool with_fv = false) {
     o.v.inv_w = pKF->mfGridElementWidthInv; o.v.inv_h = pKF->mfGridElementHeightInv;
 }
 
-// transient device residency for one call
-struct Uploaded {
-    vector<int32_t> ids;
-    Uploaded(std::initializer_list<const orbm_frame_view *> views) {
-        vector<orbm_frame_view> v;
-        for (auto p : views) v.push_back(*p);
-        ids.resize(v.size());
-        Check(orbm_frames_upload(Ctx(), (int)v.size(), v.data(), ids.data()), "orbm_frames_upload");
+// ---- residency: the device copy of a Frame / KeyFrame, uploaded on first use by this thread and kept -----------------
+template <class FrameLike>
+uint64_t Fingerprint(const FrameLike &F) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)F.N;
+    auto mix = [&h](const void *p, size_t n) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    if (F.N > 0)
+        for (int i : {0, F.N / 2, F.N - 1}) {
+            mix(F.mDescriptors.template ptr<uint8_t>(i), 32);
+            mix(&F.mvKeysUn[i].pt.x, sizeof(float)); mix(&F.mvKeysUn[i].pt.y, sizeof(float));
+            mix(&F.mvKeysUn[i].octave, sizeof(int));
+        }
+    return h;
+}
+
+void DropResident(detail::ThreadCtx &t, std::map<detail::ResKey, detail::ResEntry>::iterator it) {
+    orbm_frames_free(t.ctx, 1, &it->second.frame);
+    t.lru[it->first.kf].erase(it->second.lru);
+    t.resident.erase(it);
+}
+
+// least recently used copies beyond the limits go (never the two most recent of a kind: one call needs at most two)
+void TrimResident(detail::ThreadCtx &t) {
+    for (int kf = 0; kf < 2; kf++) {
+        const size_t limit = std::max<size_t>(4, kf ? detail::g_limit_kf.load() : detail::g_limit_frames.load());
+        while (t.lru[kf].size() > limit) DropResident(t, t.resident.find(t.lru[kf].back()));
     }
-    ~Uploaded() { orbm_frames_free(Ctx(), (int)ids.size(), ids.data()); }
+}
+struct HoldResident {             // scope of a batched call
+    detail::ThreadCtx &t;
+    HoldResident() : t(detail::Thread()) { t.hold++; }
+    ~HoldResident() { if (--t.hold == 0 && t.ctx) TrimResident(t); }
 };
+
+template <class FrameLike>
+detail::ResKey KeyOf(bool kf, const FrameLike &F) {
+    return detail::ResKey{kf, F.mnId, F.N ? (const void *)F.mDescriptors.template ptr<uint8_t>() : nullptr, F.N};
+}
+
+// id of the device copy in this thread's context; mp_flags brought up to date (they change between calls, the rest does
+// not: Frame.h:235-291 members are written once, by the constructor and ComputeBoW)
+template <class FrameLike, class Source>
+int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint *> &mps, bool with_fv) {
+    orbm_ctx *ctx = Ctx();
+    detail::ThreadCtx &t = detail::Thread();
+    const detail::ResKey key = KeyOf(kf, F);
+    const uint64_t fp = Fingerprint(F);
+    auto it = t.resident.find(key);
+    if (it != t.resident.end() && (it->second.print != fp || (with_fv && it->second.fv_size != F.mFeatVec.size()))) {
+        DropResident(t, it);          // other content under the same key, or ComputeBoW ran after the upload
+        it = t.resident.end();
+    }
+    if (it == t.resident.end()) {
+        Flat f;
+        Flatten(f, src, !F.mFeatVec.empty());
+        detail::ResEntry e;
+        Check(orbm_frames_upload(ctx, 1, &f.v, &e.frame), "orbm_frames_upload");
+        e.print = fp; e.fv_size = F.mFeatVec.size(); e.flags.swap(f.flags);
+        t.lru[kf].push_front(key);
+        e.lru = t.lru[kf].begin();
+        it = t.resident.emplace(key, std::move(e)).first;
+        const int32_t id = it->second.frame;
+        if (t.hold == 0) TrimResident(t);
+        return id;
+    }
+    detail::ResEntry &e = it->second;
+    t.lru[kf].splice(t.lru[kf].begin(), t.lru[kf], e.lru);
+    bool same = true;
+    const int n = F.N;
+    for (int i = 0; i < n; i++) {
+        const uint8_t fl = i < (int)mps.size() ? MpFlags(mps[i]) : 0;
+        if (fl != e.flags[i]) { e.flags[i] = fl; same = false; }
+    }
+    if (!same && n > 0) Check(orbm_frame_set_mp_flags(ctx, e.frame, e.flags.data()), "orbm_frame_set_mp_flags");
+    return e.frame;
+}
+
+int32_t Resident(const Frame &F, bool with_fv = false) { return Acquire(false, F, F, F.mvpMapPoints, with_fv); }
+int32_t Resident(KeyFrame *pKF, bool with_fv = false) { return Acquire(true, *pKF, pKF, pKF->GetMapPointMatches(), with_fv); }
+int32_t Resident(KeyFrame *pKF, const vector<MapPoint *> &mps, bool with_fv) { return Acquire(true, *pKF, pKF, mps, with_fv); }
 
 struct WinQ {
     vector<uint8_t> desc, flags;
@@ -190,6 +290,20 @@ void DecomposeSim3(const cv::Mat &Scw, float *Rcw, float *tcw, float *Ow) {
 }  // namespace
 
 void ORBmatcher::SetDevice(int device) { g_device = device; }
+void ORBmatcher::SetResidentLimits(size_t nKeyFrames, size_t nFrames) { detail::g_limit_kf = nKeyFrames; detail::g_limit_frames = nFrames; }
+void ORBmatcher::Prefetch(KeyFrame *pKF) { if (pKF && pKF->N > 0) Resident(pKF, true); }
+void ORBmatcher::Evict(KeyFrame *pKF) {
+    detail::ThreadCtx &t = detail::Thread();
+    if (!pKF || !t.ctx) return;
+    auto it = t.resident.find(KeyOf(true, *pKF));
+    if (it != t.resident.end()) DropResident(t, it);
+}
+void ORBmatcher::Evict(const Frame &F) {
+    detail::ThreadCtx &t = detail::Thread();
+    if (!t.ctx) return;
+    auto it = t.resident.find(KeyOf(false, F));
+    if (it != t.resident.end()) DropResident(t, it);
+}
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
@@ -215,16 +329,14 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoin
         lvl[i] = pMP->mnTrackScaleLevel; vc[i] = pMP->mTrackViewCos;
         memcpy(&desc[(size_t)i * 32], pMP->GetDescriptor().ptr<uint8_t>(), 32);
     }
-    Flat f;
-    Flatten(f, F);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(F);
     orbm_proj_queries q;
     q.n = Q; q.desc = desc.data(); q.proj_x = px.data(); q.proj_y = py.data(); q.proj_xr = pxr.data();
     q.level = lvl.data(); q.view_cos = vc.data(); q.flags = flags.data();
     int32_t qid = -1, count = 0;
     Check(orbm_proj_queries_upload(Ctx(), 1, &q, &qid), "orbm_proj_queries_upload");
     vector<int32_t> owner(F.N, -1);
-    int rc = orbm_search_proj_points_batch(Ctx(), 1, up.ids.data(), &qid, th, mfNNratio, nullptr, F.N, owner.data(), &count, 0);
+    int rc = orbm_search_proj_points_batch(Ctx(), 1, &fid, &qid, th, mfNNratio, nullptr, F.N, owner.data(), &count, 0);
     orbm_queries_free(Ctx(), 1, &qid);
     Check(rc, "orbm_search_proj_points_batch");
     for (int idx = 0; idx < F.N; idx++)
@@ -237,13 +349,10 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPo
     const vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
     vpMapPointMatches = vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));   // :225
     if (F.N == 0 || pKF->N == 0) return 0;
-    Flat a, b;
-    Flatten(a, pKF, true);
-    Flatten(b, F, true);
-    Uploaded up({&a.v, &b.v});
+    const int32_t ida = Resident(pKF, vpMapPointsKF, true), idb = Resident(F, true);
     vector<int32_t> match(F.N, -1);
     int32_t count = 0;
-    Check(orbm_search_bow_batch(Ctx(), 0, 1, &up.ids[0], &up.ids[1], mfNNratio, mbCheckOrientation ? 1 : 0, F.N, match.data(), &count, 0),
+    Check(orbm_search_bow_batch(Ctx(), 0, 1, &ida, &idb, mfNNratio, mbCheckOrientation ? 1 : 0, F.N, match.data(), &count, 0),
           "orbm_search_bow_batch");
     for (int i = 0; i < F.N; i++)
         if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];          // :312
@@ -256,17 +365,79 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
     const vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
     vpMatches12 = vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));   // :715
     if (pKF1->N == 0 || pKF2->N == 0) return 0;
-    Flat a, b;
-    Flatten(a, pKF1, true);
-    Flatten(b, pKF2, true);
-    Uploaded up({&a.v, &b.v});
+    const int32_t ida = Resident(pKF1, vpMapPoints1, true), idb = Resident(pKF2, vpMapPoints2, true);
     vector<int32_t> match(pKF1->N, -1);
     int32_t count = 0;
-    Check(orbm_search_bow_batch(Ctx(), 1, 1, &up.ids[0], &up.ids[1], mfNNratio, mbCheckOrientation ? 1 : 0, pKF1->N, match.data(), &count, 0),
+    Check(orbm_search_bow_batch(Ctx(), 1, 1, &ida, &idb, mfNNratio, mbCheckOrientation ? 1 : 0, pKF1->N, match.data(), &count, 0),
           "orbm_search_bow_batch");
     for (int i = 0; i < pKF1->N; i++)
         if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];                  // :798
     return count;
+}
+
+// ---- the candidate loops (Tracking.cc:1778-1801, LoopClosing.cc:433-477) in one launch ---------------------------------
+vector<int> ORBmatcher::SearchByBoW(const vector<KeyFrame *> &vpKFs, Frame &F, vector<vector<MapPoint *>> &vvpMapPointMatches) {
+    const int K = (int)vpKFs.size();
+    HoldResident hold;
+    vector<int> nmatches(K, 0);
+    vvpMapPointMatches.assign(K, vector<MapPoint *>());
+    vector<int32_t> ida, idb, which;
+    vector<vector<MapPoint *>> mps(K);
+    const int32_t fid = F.N > 0 ? Resident(F, true) : -1;
+    for (int k = 0; k < K; k++) {
+        KeyFrame *pKF = vpKFs[k];
+        if (!pKF || pKF->isBad()) continue;                                        // Tracking.cc:1781-1782
+        mps[k] = pKF->GetMapPointMatches();
+        vvpMapPointMatches[k] = vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
+        if (F.N == 0 || pKF->N == 0) continue;
+        ida.push_back(Resident(pKF, mps[k], true)); idb.push_back(fid); which.push_back(k);
+    }
+    const int P = (int)which.size();
+    if (P == 0) return nmatches;
+    vector<int32_t> match((size_t)P * F.N, -1), count(P, 0);
+    Check(orbm_search_bow_batch(Ctx(), 0, P, ida.data(), idb.data(), mfNNratio, mbCheckOrientation ? 1 : 0, F.N, match.data(), count.data(), 0),
+          "orbm_search_bow_batch");
+    for (int p = 0; p < P; p++) {
+        const int k = which[p];
+        const int32_t *m = &match[(size_t)p * F.N];
+        for (int i = 0; i < F.N; i++)
+            if (m[i] >= 0) vvpMapPointMatches[k][i] = mps[k][m[i]];
+        nmatches[k] = count[p];
+    }
+    return nmatches;
+}
+
+vector<int> ORBmatcher::SearchByBoW(KeyFrame *pKF1, const vector<KeyFrame *> &vpKF2s, vector<vector<MapPoint *>> &vvpMatches12) {
+    const int K = (int)vpKF2s.size();
+    HoldResident hold;
+    vector<int> nmatches(K, 0);
+    vvpMatches12.assign(K, vector<MapPoint *>());
+    const vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = pKF1->N;
+    vector<int32_t> ida, idb, which;
+    vector<vector<MapPoint *>> mps(K);
+    const int32_t id1 = N1 > 0 ? Resident(pKF1, vpMapPoints1, true) : -1;
+    for (int k = 0; k < K; k++) {
+        KeyFrame *pKF2 = vpKF2s[k];
+        if (!pKF2 || pKF2->isBad()) continue;                                      // LoopClosing.cc:441-445
+        mps[k] = pKF2->GetMapPointMatches();
+        vvpMatches12[k] = vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));
+        if (N1 == 0 || pKF2->N == 0) continue;
+        ida.push_back(id1); idb.push_back(Resident(pKF2, mps[k], true)); which.push_back(k);
+    }
+    const int P = (int)which.size();
+    if (P == 0) return nmatches;
+    vector<int32_t> match((size_t)P * N1, -1), count(P, 0);
+    Check(orbm_search_bow_batch(Ctx(), 1, P, ida.data(), idb.data(), mfNNratio, mbCheckOrientation ? 1 : 0, N1, match.data(), count.data(), 0),
+          "orbm_search_bow_batch");
+    for (int p = 0; p < P; p++) {
+        const int k = which[p];
+        const int32_t *m = &match[(size_t)p * N1];
+        for (int i = 0; i < N1; i++)
+            if (m[i] >= 0) vvpMatches12[k][i] = mps[k][m[i]];
+        nmatches[k] = count[p];
+    }
+    return nmatches;
 }
 
 // ---- ORBmatcher.cc:562-689 ----------------------------------------------------------------------------------------
@@ -274,14 +445,11 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
     const int n1 = (int)F1.mvKeysUn.size();
     vnMatches12 = vector<int>(n1, -1);            // :566
     if (n1 == 0 || F2.N == 0) return 0;
-    Flat a, b;
-    Flatten(a, F1);
-    Flatten(b, F2);
-    Uploaded up({&a.v, &b.v});
+    const int32_t ida = Resident(F1), idb = Resident(F2);
     vector<float> prev((size_t)n1 * 2);
     for (int i = 0; i < n1; i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
     vector<int32_t> m12(n1, -1);
-    int n = orbm_search_init(Ctx(), up.ids[0], up.ids[1], prev.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data());
+    int n = orbm_search_init(Ctx(), ida, idb, prev.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data());
     Check(n, "orbm_search_init");
     for (int i = 0; i < n1; i++) {
         vnMatches12[i] = m12[i];
@@ -300,15 +468,12 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     const float epi[2] = {pKF2->fx * C2[0] * invz + pKF2->cx, pKF2->fy * C2[1] * invz + pKF2->cy};
     vMatchedPairs.clear();
     if (pKF1->N == 0 || pKF2->N == 0) return 0;
-    Flat a, b;
-    Flatten(a, pKF1, true);
-    Flatten(b, pKF2, true);
-    Uploaded up({&a.v, &b.v});
+    const int32_t ida = Resident(pKF1, true), idb = Resident(pKF2, true);
     float f12[9];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) f12[3 * r + c] = F12.at<float>(r, c);
     vector<int32_t> m12(pKF1->N, -1);
     int32_t count = 0;
-    Check(orbm_search_triang_batch(Ctx(), 1, &up.ids[0], &up.ids[1], f12, epi, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+    Check(orbm_search_triang_batch(Ctx(), 1, &ida, &idb, f12, epi, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
                                    pKF1->N, m12.data(), &count, 0), "orbm_search_triang_batch");
     vMatchedPairs.reserve(count);
     for (size_t i = 0; i < m12.size(); i++)                                           // :1085-1090
@@ -356,11 +521,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         q.flags[i] = ORBM_Q_VALID | (pMP->Observations() > 0 ? ORBM_Q_OBS : 0);
         q.SetDesc(i, pMP->GetDescriptor());
     }
-    Flat f;
-    Flatten(f, CurrentFrame);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(CurrentFrame);
     vector<int32_t> owner;
-    const int n = q.Run(0, up.ids[0], CurrentFrame.N, TH_HIGH, mbCheckOrientation, true, true, nullptr, owner);
+    const int n = q.Run(0, fid, CurrentFrame.N, TH_HIGH, mbCheckOrientation, true, true, nullptr, owner);
     for (int idx = 0; idx < CurrentFrame.N; idx++) {
         if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = LastFrame.mvpMapPoints[owner[idx]];   // :1906
         else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = static_cast<MapPoint *>(NULL);  // :1942
@@ -404,11 +567,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
         q.flags[i] = ORBM_Q_VALID | ORBM_Q_OBS;
         q.SetDesc((int)i, pMP->GetDescriptor());
     }
-    Flat f;
-    Flatten(f, CurrentFrame);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(CurrentFrame);
     vector<int32_t> owner;
-    const int n = q.Run(1, up.ids[0], CurrentFrame.N, ORBdist, mbCheckOrientation, false, true, nullptr, owner);
+    const int n = q.Run(1, fid, CurrentFrame.N, ORBdist, mbCheckOrientation, false, true, nullptr, owner);
     for (int idx = 0; idx < CurrentFrame.N; idx++) {
         if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = vpMPs[owner[idx]];        // :2066
         else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = NULL;               // :2115
@@ -453,13 +614,11 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapP
         q.flags[iMP] = ORBM_Q_VALID | ORBM_Q_OBS;
         q.SetDesc(iMP, pMP->GetDescriptor());
     }
-    Flat f;
-    Flatten(f, pKF);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(pKF);
     vector<uint8_t> slot(pKF->N, 0);
     for (int i = 0; i < pKF->N && i < (int)vpMatched.size(); i++) slot[i] = vpMatched[i] ? ORBM_MP_PRESENT : 0;   // :512
     vector<int32_t> owner;
-    const int n = q.Run(2, up.ids[0], pKF->N, TH_LOW, false, false, false, slot.data(), owner);
+    const int n = q.Run(2, fid, pKF->N, TH_LOW, false, false, false, slot.data(), owner);
     for (int idx = 0; idx < pKF->N; idx++)
         if (owner[idx] >= 0) vpMatched[idx] = vpPoints[owner[idx]];                       // :535
     return n;
@@ -524,12 +683,9 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> 
     WinQ q1(N1), q2(N2);
     build(q1, vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2);
     build(q2, vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12.ptr<float>(), pKF1);
-    Flat f1, f2;
-    Flatten(f1, pKF1);
-    Flatten(f2, pKF2);
-    Uploaded up({&f1.v, &f2.v});
+    const int32_t id1 = Resident(pKF1, vpMapPoints1, false), id2 = Resident(pKF2, vpMapPoints2, false);
     vector<vector<int32_t>> best;
-    RunFree({&q1, &q2}, {up.ids[1], up.ids[0]}, TH_HIGH, false, best);                   // both directions, one launch
+    RunFree({&q1, &q2}, {id2, id1}, TH_HIGH, false, best);                   // both directions, one launch
     const vector<int32_t> &vnMatch1 = best[0], &vnMatch2 = best[1];
     int nFound = 0;
     for (int i1 = 0; i1 < N1; i1++) {                                                     // :1736-1749
@@ -594,11 +750,9 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
     }
     WinQ q(nMPs);
     FuseQueries(q, pKF, vpMapPoints, skip, Rcw.ptr<float>(), tcw.ptr<float>(), Ow.ptr<float>(), pKF->mbf, th);
-    Flat f;
-    Flatten(f, pKF);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(pKF);
     vector<vector<int32_t>> best;
-    RunFree({&q}, {up.ids[0]}, TH_LOW, true, best);
+    RunFree({&q}, {fid}, TH_LOW, true, best);
     // replay of the reference loop, in order, with the state-dependent gates evaluated now
     int nFused = 0;
     for (int i = 0; i < nMPs; i++) {
@@ -633,11 +787,9 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     for (int i = 0; i < nPoints; i++) skip[i] = vpPoints[i]->isBad() || spAlreadyFound.count(vpPoints[i]);   // :1337 (nothing here makes a point bad)
     WinQ q(nPoints);
     FuseQueries(q, pKF, vpPoints, skip, Rcw, tcw, Ow, 0.f, th);
-    Flat f;
-    Flatten(f, pKF);
-    Uploaded up({&f.v});
+    const int32_t fid = Resident(pKF);
     vector<vector<int32_t>> best;
-    RunFree({&q}, {up.ids[0]}, TH_LOW, false, best);
+    RunFree({&q}, {fid}, TH_LOW, false, best);
     int nFused = 0;
     for (int iMP = 0; iMP < nPoints; iMP++) {
         const int bestIdx = best[0][iMP];

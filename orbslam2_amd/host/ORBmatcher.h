@@ -19,7 +19,18 @@
 #include <utility>
 #include <vector>
 
+// In an ORB-SLAM2 tree (built with -DORBMATCH_USE_OPENCV) the types come from the project's own headers, exactly as
+// the reference's ORBmatcher.h:29-31 includes them; stand-alone builds and the tests use the stand-ins.
+#ifdef ORBMATCH_USE_OPENCV
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>
+
+#include "MapPoint.h"
+#include "KeyFrame.h"
+#include "Frame.h"
+#else
 #include "orbslam_types.h"
+#endif
 
 namespace ORB_SLAM2 {
 
@@ -63,8 +74,29 @@ public:
     static const int TH_HIGH;
     static const int HISTO_LENGTH;
 
-    // Extension (not in the reference): GPU the calling thread's searches run on; default 0 or $ORBMATCH_DEVICE.
+    // ---- extensions (not in the reference) -----------------------------------------------------------------------
+    // GPU the searches run on (contexts created after the call); default 0 or $ORBMATCH_DEVICE.
     static void SetDevice(int device);
+
+    // Device residency.  Every Frame / KeyFrame a thread searches is uploaded ONCE into that thread's context
+    // (descriptors, keypoints, FeatureVector; the grid is built on the device) and found again by
+    // (mnId, descriptor buffer, N) + a content fingerprint; later calls only refresh the map-point flags when they
+    // changed.  Prefetch uploads ahead of the first search -- the natural place is keyframe creation, after
+    // ComputeBoW (KeyFrame.cc:46-78, LocalMapping.cc:ProcessNewKeyFrame).  Evict drops the calling thread's copy
+    // (call it from KeyFrame::SetBadFlag / before deleting a keyframe; copies are also dropped least-recently-used
+    // first beyond the limits, default 16384 keyframes and 8 frames per thread).
+    static void Prefetch(KeyFrame *pKF);
+    static void Evict(KeyFrame *pKF);
+    static void Evict(const Frame &F);
+    static void SetResidentLimits(size_t nKeyFrames, size_t nFrames);
+
+    // The candidate loops around SearchByBoW as ONE launch: Tracking::Relocalization (Tracking.cc:1778-1801,
+    // `matcher.SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i])` for every candidate) and
+    // LoopClosing::ComputeSim3 (LoopClosing.cc:433-477, `matcher.SearchByBoW(mpCurrentKF, pKF, vvpMapPointMatches[i])`).
+    // Entry i of the result / of vvp... is exactly what the i-th call of the loop returns; a NULL or bad candidate
+    // (the loops `continue` on isBad()) gets 0 and an empty vector.
+    std::vector<int> SearchByBoW(const std::vector<KeyFrame *> &vpKFs, Frame &F, std::vector<std::vector<MapPoint *>> &vvpMapPointMatches);
+    std::vector<int> SearchByBoW(KeyFrame *pKF1, const std::vector<KeyFrame *> &vpKF2s, std::vector<std::vector<MapPoint *>> &vvpMatches12);
 
 protected:
     float mfNNratio;

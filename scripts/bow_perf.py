@@ -10,7 +10,7 @@ torch.cuda.init()
 dev = torch.device("cuda:0")
 ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-kfs, ids = bench.build_store(ctx, 20161011 + 2)
+kfs, ids = bench.build_store(ctx, 96)
 P = 8192
 rng = np.random.default_rng(3)
 a = rng.integers(0, len(ids), P)
@@ -18,7 +18,11 @@ mixes = {"bench mix": bench.pair_list(np.random.default_rng(3), ids, P),
          "neighbours": (ids[a].astype(np.int32), ids[(a + rng.integers(1, 4, P)) % len(ids)].astype(np.int32)),
          "far": (ids[a].astype(np.int32), ids[(a + rng.integers(30, 60, P)) % len(ids)].astype(np.int32))}
 match = torch.empty((P, bench.N_FEAT), dtype=torch.int32, device=dev); counts = torch.empty(P, dtype=torch.int32, device=dev)
-for variant in (1, 0):
+from orbslam2_amd import _lib
+L = _lib.load()
+for form in (2,):
+  L.orbm__bow_variant(form)
+  for variant in (1, 0):
     for name, (fa, fb) in mixes.items():
         tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
         best = 1e30
@@ -29,5 +33,6 @@ for variant in (1, 0):
             e1.record(); torch.cuda.synchronize()
             if rep:
                 best = min(best, e0.elapsed_time(e1))
-        print("variant %d %-10s %.3f ms  %.2f M pairs/s  mean matches %.1f" % (variant, name, best, P / best / 1e3, counts.float().mean().item()), flush=True)
+        print("form %d variant %d %-10s %.3f ms  %.2f M pairs/s  mean matches %.1f" % (form, variant, name, best, P / best / 1e3, counts.float().mean().item()), flush=True)
+L.orbm__bow_variant(0)
 ctx.close()

@@ -24,7 +24,7 @@ for extra_pass in ("sq2", "sq3"):
     except Exception:
         pass
 bf = [r for r in rows if HEAD in r["Name"]][0]
-P, N = 4096, 2000
+P, N = int(os.environ.get("ORBM_PROF_PAIRS", "16384")), 2000     # pairs per orbm_allpairs_batch launch (bench.py PAIRS_PER_LAUNCH)
 alg_bytes = P * (2 * N * 128 + N * 4 + 4)     # both +-1 FP4 images (128 B per descriptor) once per pair + match row + count
 # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # 16-byte-per-lane coalesced reads (our staging and query loads) -> doubled
@@ -40,6 +40,7 @@ summ = {"tag": tag, "kernel": bf["Name"][:80], "launches_profiled": int(bf["Call
 # integer peak, the evidence BASELINE's north star asks for
 try:
     VK = "bf2nn_kernel<2, 4, 0>"
+    P = 4096                                                      # bench.py popcount_form()
     vsq, _ = counters("sq", VK)
     for extra_pass in ("sq2",):
         more, _ = counters(extra_pass, VK); vsq.update(more)

@@ -12,6 +12,7 @@
 #include <memory>
 #include <random>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbmatch.h"
@@ -22,6 +23,12 @@
 
 using namespace ORB_SLAM2;
 using std::vector;
+
+// Frame's static members: in an ORB-SLAM2 tree Frame.cc:32-34 defines them; this stand-alone build does it here (the
+// drop-in library must not, or the two definitions would collide at link time).
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy;
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
 
 extern "C" {
 int orc_search_bow(int variant, const orbm_frame_view *A, const orbm_frame_view *B, float ratio, int check_ori, int32_t *match, uint64_t *ncmp);
@@ -142,8 +149,10 @@ template <class T> static void FillCommon(T &F, const Raw &r) {
     F.mvScaleFactors = r.sf; F.mvLevelSigma2 = r.sigma2;
     F.mvInvLevelSigma2.resize(8); for (int i = 0; i < 8; i++) F.mvInvLevelSigma2[i] = 1.0f / r.sigma2[i];
 }
+static long unsigned int g_next_frame_id = 1, g_next_kf_id = 1000;   // Frame::nNextId / KeyFrame::nNextId: unique ids, as in the reference
 static void FillFrame(Frame &F, const Raw &r) {
     FillCommon(F, r);
+    F.mnId = g_next_frame_id++;
     F.mvbOutlier.assign(r.n, false);
     Frame::fx = 500; Frame::fy = 510; Frame::cx = 320; Frame::cy = 240;
     Frame::mnMinX = 0; Frame::mnMinY = 0; Frame::mnMaxX = 640; Frame::mnMaxY = 480;
@@ -153,6 +162,7 @@ static void FillFrame(Frame &F, const Raw &r) {
 }
 static void FillKF(KeyFrame &K, const Raw &r) {
     FillCommon(K, r);
+    K.mnId = g_next_kf_id++;
     K.fx = 500; K.fy = 510; K.cx = 320; K.cy = 240; K.mbf = 40;
     K.mnMinX = 0; K.mnMinY = 0; K.mnMaxX = 640; K.mnMaxY = 480;
     K.mfGridElementWidthInv = 64.f / 640.f; K.mfGridElementHeightInv = 48.f / 480.f;
@@ -200,6 +210,125 @@ static void TestBoW() {
         printf("latency SearchByBoW(KF,F) 2000x2000: %.3f ms per call\n", (NowMs() - t0) / 20);
     }
     printf("SearchByBoW x2 done\n");
+}
+
+
+// Residency: the second call on the same objects finds the device copies; what changed in between (map points added,
+// gone bad, a FeatureVector computed after the first upload, an object re-filled with another image under the same id)
+// must be seen.  Then the batched candidate loops against the per-candidate calls.
+static void TestResidency() {
+    vector<Desc> lm(1600); for (auto &d : lm) d = RandDesc();
+    Raw ra = MakeRaw(900, lm, 0, 1200, 12, 0.3, 0.85, 0.05, 0.1), rb = MakeRaw(800, lm, 400, 1200, 12, 0.3, 0.8, 0.05, 0.1);
+    KeyFrame A, B; Frame F;
+    FillKF(A, ra); FillKF(B, rb); FillFrame(F, rb);
+    ORBmatcher matcher(0.75f, true);
+    ORBmatcher::Prefetch(&A);
+    auto check = [&](const char *what) {
+        orbm_frame_view va = ra.view(true), vb = rb.view(true);
+        vector<int32_t> m(rb.n), m2(ra.n); uint64_t nc;
+        int want = orc_search_bow(0, &va, &vb, 0.75f, 1, m.data(), &nc);
+        vector<MapPoint *> got;
+        int cnt = matcher.SearchByBoW(&A, F, got);
+        int bad = 0;
+        for (int i = 0; i < F.N; i++) bad += got[i] != (m[i] >= 0 ? A.mvpMapPoints[m[i]] : nullptr);
+        EXPECT(cnt == want && bad == 0, "%s: KF-F count %d vs %d, %d pointer mismatches", what, cnt, want, bad);
+        want = orc_search_bow(1, &va, &vb, 0.75f, 1, m2.data(), &nc);
+        cnt = matcher.SearchByBoW(&A, &B, got);
+        bad = 0;
+        for (int i = 0; i < A.N; i++) bad += got[i] != (m2[i] >= 0 ? B.mvpMapPoints[m2[i]] : nullptr);
+        EXPECT(cnt == want && bad == 0, "%s: KF-KF count %d vs %d, %d pointer mismatches", what, cnt, want, bad);
+        return want;
+    };
+    const int first = check("first use");
+    check("second use (resident)");
+    // map points change between calls: a fifth of A's and B's go bad or disappear, some empty slots get one
+    auto churn = [&](auto &K, Raw &r) {
+        for (int i = 0; i < r.n; i++) {
+            const double u = U(0, 1);
+            if (u < 0.1 && K.mvpMapPoints[i]) { K.mvpMapPoints[i]->mbBad = true; r.flags[i] |= ORBM_MP_BAD; }
+            else if (u < 0.2) { K.mvpMapPoints[i] = nullptr; r.flags[i] = 0; }
+            else if (u < 0.3 && !K.mvpMapPoints[i]) { r.flags[i] = ORBM_MP_PRESENT | ORBM_MP_OBS; K.mvpMapPoints[i] = NewMP(r.flags[i], &r.desc[i]); }
+        }
+    };
+    churn(A, ra); churn(B, rb);
+    const int after = check("after the map points changed");
+    EXPECT(after != first, "the churn should change the result (%d both times): the test is not sensitive", after);
+    // a Frame uploaded before ComputeBoW (Tracking searches a frame before it computes its BoW), then used with its FeatureVector
+    {
+        Raw rq = MakeRaw(700, lm, 400, 1200, 12, 0.3, 0.0, 0, 0);
+        Frame G; FillFrame(G, rq);
+        DBoW2::FeatureVector keep; keep.swap(G.mFeatVec);            // not computed yet
+        {
+            vector<cv::Point2f> prev(rq.n); for (int i = 0; i < rq.n; i++) prev[i] = cv::Point2f(rq.x[i], rq.y[i]);
+            vector<int> m12;
+            matcher.SearchForInitialization(G, G, prev, m12, 10);    // uploads G without a FeatureVector
+        }
+        G.mFeatVec.swap(keep);                                       // ComputeBoW
+        orbm_frame_view va = ra.view(true), vq = rq.view(false);
+        vector<int32_t> m(rq.n); uint64_t nc;
+        const int want = orc_search_bow(0, &va, &vq, 0.75f, 1, m.data(), &nc);
+        vector<MapPoint *> got;
+        const int cnt = matcher.SearchByBoW(&A, G, got);
+        int bad = 0;
+        for (int i = 0; i < G.N; i++) bad += got[i] != (m[i] >= 0 ? A.mvpMapPoints[m[i]] : nullptr);
+        EXPECT(cnt == want && bad == 0 && want > 10, "FeatureVector after upload: count %d vs %d, %d mismatches", cnt, want, bad);
+        // the same object refilled with another image under the SAME id and buffer (what a fingerprint is for)
+        Raw rq2 = MakeRaw(700, lm, 0, 1200, 12, 0.3, 0.0, 0, 0);
+        for (int i = 0; i < rq2.n; i++) {
+            memcpy(G.mDescriptors.ptr<uint8_t>(i), rq2.desc[i].b, 32);
+            G.mvKeysUn[i].pt = cv::Point2f(rq2.x[i], rq2.y[i]); G.mvKeysUn[i].angle = rq2.angle[i]; G.mvKeysUn[i].octave = rq2.octave[i];
+            G.mvKeys[i] = G.mvKeysUn[i];
+        }
+        G.mvuRight = rq2.uright; G.mFeatVec.clear();
+        for (size_t k = 0; k < rq2.fv_node.size(); k++)
+            for (uint32_t j = rq2.fv_off[k]; j < rq2.fv_off[k + 1]; j++) G.mFeatVec[rq2.fv_node[k]].push_back(rq2.fv_idx[j]);
+        orbm_frame_view vq2 = rq2.view(false);
+        const int want2 = orc_search_bow(0, &va, &vq2, 0.75f, 1, m.data(), &nc);
+        const int cnt2 = matcher.SearchByBoW(&A, G, got);
+        bad = 0;
+        for (int i = 0; i < G.N; i++) bad += got[i] != (m[i] >= 0 ? A.mvpMapPoints[m[i]] : nullptr);
+        EXPECT(cnt2 == want2 && bad == 0, "refilled object: count %d vs %d, %d mismatches", cnt2, want2, bad);
+        ORBmatcher::Evict(G);
+    }
+    // the candidate loops in one launch (Tracking.cc:1778-1801, LoopClosing.cc:433-477) = the per-candidate calls
+    {
+        const int K = 12;
+        vector<Raw> rk; vector<std::unique_ptr<KeyFrame>> ks; vector<KeyFrame *> cand;
+        for (int k = 0; k < K; k++) {
+            rk.push_back(MakeRaw(500 + 40 * k, lm, 100 * k, 1200, 12, 0.3, 0.85, 0.05, 0.1));
+            ks.emplace_back(new KeyFrame()); FillKF(*ks.back(), rk.back()); cand.push_back(ks.back().get());
+        }
+        cand[3]->mbBad = true; cand.insert(cand.begin() + 7, nullptr);
+        vector<vector<MapPoint *>> all;
+        const vector<int> n = matcher.SearchByBoW(cand, F, all);
+        int bad = 0, tot = 0;
+        for (size_t k = 0; k < cand.size(); k++) {
+            if (!cand[k] || cand[k]->isBad()) { bad += n[k] != 0 || !all[k].empty(); continue; }
+            vector<MapPoint *> one;
+            const int c = matcher.SearchByBoW(cand[k], F, one);
+            bad += c != n[k] || one != all[k]; tot += c;
+        }
+        EXPECT(bad == 0 && tot > 50, "batched SearchByBoW(KFs, F): %d candidates differ from the single calls (%d matches in all)", bad, tot);
+        const vector<int> n2 = matcher.SearchByBoW(&A, cand, all);
+        bad = 0; tot = 0;
+        for (size_t k = 0; k < cand.size(); k++) {
+            if (!cand[k] || cand[k]->isBad()) { bad += n2[k] != 0 || !all[k].empty(); continue; }
+            vector<MapPoint *> one;
+            const int c = matcher.SearchByBoW(&A, cand[k], one);
+            bad += c != n2[k] || one != all[k]; tot += c;
+        }
+        EXPECT(bad == 0 && tot > 50, "batched SearchByBoW(KF, KFs): %d candidates differ from the single calls (%d matches in all)", bad, tot);
+        double t0 = NowMs();
+        { vector<vector<MapPoint *>> tmp; for (int r = 0; r < 20; r++) matcher.SearchByBoW(cand, F, tmp); }
+        printf("latency SearchByBoW(%d candidate KFs, F) batched, resident: %.3f ms per call\n", K, (NowMs() - t0) / 20);
+        // least-recently-used eviction: with room for 4 keyframes every candidate is uploaded again, results unchanged
+        ORBmatcher::SetResidentLimits(4, 4);
+        vector<vector<MapPoint *>> again;
+        const vector<int> n3 = matcher.SearchByBoW(&A, cand, again);
+        EXPECT(n3 == n2 && again == all, "results changed under a residency limit of 4 keyframes");
+        ORBmatcher::SetResidentLimits(16384, 8);
+    }
+    printf("residency + batched candidate loops done\n");
 }
 
 static void TestInit() {
@@ -408,6 +537,13 @@ static void TestWindowOverloads() {
             vector<MapPoint *> before = Cur.mvpMapPoints;
             cnt = matcher.SearchByProjection(Cur, Last, 7.0f, false);
             for (int i = 0; i < rc.n; i++) bad += Cur.mvpMapPoints[i] != (owner[i] >= 0 ? Last.mvpMapPoints[owner[i]] : owner[i] == -2 ? nullptr : before[i]);
+            if (ori == 1) {   // per-call latency with the current frame resident (its slot vector is restored before every call)
+                const vector<MapPoint *> after = Cur.mvpMapPoints;
+                double t0 = NowMs();
+                for (int r = 0; r < 20; r++) { Cur.mvpMapPoints = before; matcher.SearchByProjection(Cur, Last, 7.0f, false); }
+                printf("latency SearchByProjection(Cur, Last, th=7) %d points into %d kp, resident: %.3f ms per call\n", Last.N, Cur.N, (NowMs() - t0) / 20);
+                EXPECT(Cur.mvpMapPoints == after, "repeated SearchByProjection(Cur, Last) calls differ");
+            }
         } else if (mode == 1) {
             want = orc_search_window(1, &vt, &wq, 64, ori, nullptr, owner.data(), &nc);
             vector<MapPoint *> before = Cur.mvpMapPoints;
@@ -923,6 +1059,7 @@ int main() {
         EXPECT(ORBmatcher::DescriptorDistance(a, b) == 256 && ORBmatcher::DescriptorDistance(a, a) == 0, "DescriptorDistance");
         EXPECT(ORBmatcher::TH_LOW == 50 && ORBmatcher::TH_HIGH == 100 && ORBmatcher::HISTO_LENGTH == 30, "constants");
         TestBoW();
+        TestResidency();
         TestInit();
         TestTriang();
         TestProjPoints();
