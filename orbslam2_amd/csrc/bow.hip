@@ -667,8 +667,10 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
     if (tid == 0) counts[p] = pair_acc[p * 32 + 30] - removed_all;
 }
 
-// tuning / test knob: 0 = auto (large batches: queries on lanes, bowq_kernel; small batches, where several workgroups
-// share a pair and a wave gets one or two nodes: candidates on lanes, bow_kernel), 1 = bow_kernel always, 2 = bowq_kernel always
+// tuning / test knob: 0 = auto (batches of g_bow_split_below pairs and more: the matrix-core form of bowm.hip for a7 / a8,
+// bowq_kernel for a9; smaller batches share a pair between several workgroups: queries on lanes (bowq_kernel) above 96
+// pairs, candidates on lanes (bow_kernel) below), 1 = bow_kernel always, 2 = bowq_kernel always, 3 = bowq_kernel with one
+// workgroup per pair whatever the batch size, 5 = the matrix-core form whatever the batch size
 int g_bow_variant = 0;
 int g_bow_split_below = 2048;   // batches of fewer pairs share each pair between several workgroups
 
@@ -701,6 +703,17 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         }
     }
     const size_t out_elems = (size_t)n_pairs * stride;
+    // Large batches of a7 / a8 take the matrix-core form (bowm.hip) when the ratio leaves few distances relevant; it reads
+    // the FeatureVector-ordered FP4 image of the frames, built here on first use (before anything is staged: the build
+    // uses the same staging buffers)
+    const int capd = orbm_bow_cap(ratio);
+    const bool one_wg_per_pair = !static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3 || g_bow_variant == 5);
+    const bool use_mfma = mode != 2 && one_wg_per_pair && capd <= 128 && (g_bow_variant == 0 || g_bow_variant == 5);
+    if (use_mfma) {
+        int rc = io_on_device ? orbm_ensure_image(ctx, 5, 0, nullptr) : orbm_ensure_image(ctx, 5, n_pairs, frame_a);
+        if (!rc && !io_on_device) rc = orbm_ensure_image(ctx, 5, n_pairs, frame_b);
+        if (rc) return rc;
+    }
     IoStage io(ctx, io_on_device);
     if (!io_on_device) {
         int rc = orbm_ws_reserve(ctx, (size_t)n_pairs * (12 + 44) + out_elems * 4 + 8192);
@@ -718,10 +731,13 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
     // 64 / 256 / 512 / 1024 pairs 0.050 / 0.078 / 0.114 / 0.167 ms against 0.056 / 0.130 / 0.181 / 0.203 ms with one policy for all).
     const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
-    const int splits = (!static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3)) ? 1
+    const int splits = one_wg_per_pair ? 1
                        : std::max(2, std::min(split_queries_on_lanes ? 16 : 32, (4096 + n_pairs - 1) / n_pairs));
     dim3 block(256);
-    if (splits == 1) {
+    if (use_mfma) {
+        rc = orbm_launch_bowm(ctx, mode, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, capd, check_ori, stride, (int32_t *)dm, (int32_t *)dc);
+        if (rc) return rc;
+    } else if (splits == 1) {
         dim3 grid(n_pairs);
 #define LAUNCH(M)                                                                                              \
     hipLaunchKernelGGL((g_bow_variant == 1 ? bow_kernel<M, false> : bowq_kernel<M, false>), grid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \

@@ -1,0 +1,350 @@
+// bowm.hip -- SearchByBoW (a7: ORBmatcher.cc:218-385, a8: :703-854) for LARGE batches of keyframe pairs, distances on the
+// matrix cores.
+//
+// What the reference computes per common vocabulary node is a small dense block: every query of the node against every
+// candidate of the node (about 20 x 20 for 2000 features over 100 nodes).  With the descriptor bits as +-1 (FP4 E2M1, exact)
+// a 32 x 32 block of Hamming distances is four v_mfma_scale_f32_32x32x64_f8f6f4 (d = (256 - dot) / 2, see bf2nn.hip).  A
+// node's rows are CONSECUTIVE in the FeatureVector-ordered copy of the descriptors (FrameDev::descfv, 32 bytes per row), so
+// an operand is ONE coalesced 16-byte load per lane; the bits become FP4 values in registers (7 vector instructions per 32
+// bits, expand_fp4) -- the pre-expanded image the brute-force search uses would move four times the bytes, and this path
+// has no operand reuse to pay for them.  No LDS staging, no per-candidate loop.
+//
+// What the reference DECIDES per query depends on very few of those distances.  It accepts a query's best candidate iff
+// bestDist1 <= TH_LOW (a7; '<' in a8) and (float)bestDist1 < ratio * (float)bestDist2 (:304-308 / :792-796).  Let capd be the
+// smallest distance with ratio * (float)capd > TH_LOW: any second-best distance >= capd passes the ratio test for every
+// acceptable best distance, exactly as "no second candidate" (256) does.  So only candidates with d < capd ("relevant":
+// 67 for ratio 0.75, 84 for 0.6) can change a result, and between descriptors of different landmarks they are rare.  The
+// wave folds the 16 dots a lane holds with v_max3 against that one threshold; only when some lane passes does it look at
+// the values and append (query position, distance, candidate position) records to a short list in LDS.  The claims
+// (vpMapPointMatches[idxF] / vbMatched2[idx2], which only couple queries of the SAME node because a keypoint belongs to
+// one node) are then settled on the list alone:
+//   * the usual case, no two records share a query or a candidate: every record decides for itself (second best = none);
+//   * otherwise the records are taken query by query in the reference's order (ascending position in the node), best and
+//     second best among the query's records whose candidate is still free, a claim removes the candidate for later queries;
+//   * a node with more records than lanes, or too large for the record format, falls back to the generic loop (queries in
+//     order, 64 lanes over the candidates, claimed bits in LDS): the same code path as bow_kernel in bow.hip.
+// Rotation histogram, ComputeThreeMaxima and the erase pass as in bow.hip.  One 256-thread workgroup per pair, a wave takes
+// every fourth node of the a-side FeatureVector.
+#include <algorithm>
+#include "orbm_internal.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
+constexpr int MAX_N = 65536;
+constexpr int BM_LIST = 128;          // records a wave can hold per node (more than 64 -> generic loop)
+constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
+
+__device__ __forceinline__ void load_row(gptr<const uint32_t> desc, int idx, uint32_t (&r)[8]) {
+    const gptr<const v4u> p = (gptr<const v4u>)desc + 2 * (size_t)idx;
+    const v4u lo = p[0], hi = p[1];
+    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
+}
+
+__device__ __forceinline__ void wave_top2(uint32_t &best, uint32_t &second) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t ob = __shfl_xor(best, off, 64), os = __shfl_xor(second, off, 64);
+        const uint32_t nb = min(best, ob);
+        second = min(max(best, ob), min(second, os));
+        best = nb;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ int find_node(gptr<const uint32_t> nodes, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nodes[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && nodes[lo] == key) ? lo : -1;
+}
+
+// 32 descriptor bits -> 32 FP4 values (+1.0 = 0x2 for a 0 bit, -1.0 = 0xA for a 1 bit), eight per dword: dword k takes bits
+// k, k + 4, ..., k + 28, which already sit at the nibble positions.  7 vector instructions.
+__device__ __forceinline__ v8i expand_fp4(uint32_t w) {
+    return (v8i){(int)(((w & 0x11111111u) << 3) | 0x22222222u), (int)(((w & 0x22222222u) << 2) | 0x22222222u),
+                 (int)(((w & 0x44444444u) << 1) | 0x22222222u), (int)((w & 0x88888888u) | 0x22222222u), 0, 0, 0, 0};
+}
+
+// MODE 0: a7 (KF -> F), 1: a8 (KF -> KF)
+template <int MODE>
+__global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+                                                   const int32_t *__restrict__ fb, float ratio, int capd, int check_ori, int stride,
+                                                   int32_t *__restrict__ match_all, int32_t *__restrict__ counts) {
+    __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
+    __shared__ uint32_t s_list[4][BM_LIST];
+    __shared__ int s_cnt[4];
+    __shared__ int hist[ORBM_HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int nmatches;
+    const int p = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const int nOut = MODE == 0 ? B.n : A.n;
+    int32_t *match = match_all + (size_t)p * stride;
+    for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
+    if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) nmatches = 0;
+    __syncthreads();
+
+    const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
+    const int thr = MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW;          // :304 / :792
+    const float Tf = (float)(256 - 2 * capd);                          // dot > Tf  <=>  distance < capd
+    const int one = 0x7F7F7F7F;                                        // E8M0 block scale 2^0 in every byte
+    const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
+    uint32_t *list = s_list[wave];
+    int *cnt = &s_cnt[wave];
+    int my_matches = 0;
+
+    auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815
+        if (MODE == 0) match[idxB] = idxA; else match[idxA] = idxB;
+        if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[idxB])], 1);
+        my_matches++;
+    };
+
+    // the reference's loops as they stand, for one node: queries in order, the 64 lanes over the candidates
+    auto generic_node = [&](uint32_t offA, uint32_t nA, uint32_t offB, uint32_t nB) {
+        for (uint32_t qa = 0; qa < nA; qa++) {
+            const int idxA = (int)A.fv_idx[offA + qa];
+            const uint32_t fA = A.mp_flags[idxA];
+            if (!(fA & ORBM_MP_PRESENT) || (fA & ORBM_MP_BAD)) continue;                  // :263-267 / :746-749
+            uint32_t q[8];
+            load_row(A.desc, idxA, q);
+            uint32_t best = INITKEY, second = INITKEY;
+            for (uint32_t cb = 0; cb < nB; cb += 64) {
+                const uint32_t c = cb + (uint32_t)lane;
+                if (c >= nB) continue;
+                const int idxB = (int)B.fv_idx[offB + c];
+                if (MODE == 1) {
+                    const uint32_t fl = B.mp_flags[idxB];
+                    if (!(fl & ORBM_MP_PRESENT) || (fl & ORBM_MP_BAD)) continue;          // :766-770
+                }
+                if ((claimed[idxB >> 5] >> (idxB & 31)) & 1u) continue;                   // :282 / :766
+                uint32_t cd[8];
+                load_row(B.desc, idxB, cd);
+                const uint32_t key = (hamming256(q, cd) << 16) | c;
+                second = umed3(best, second, key);
+                best = min(best, key);
+            }
+            wave_top2(best, second);
+            const int bd = (int)(best >> 16), sd = (int)(second >> 16);
+            if (bd <= thr && (float)bd < __fmul_rn(ratio, (float)sd)) {                    // :304-308 / :792-796
+                const int idxB = (int)B.fv_idx[offB + (best & 0xFFFFu)];
+                if (lane == 0) {
+                    atomicOr(&claimed[idxB >> 5], 1u << (idxB & 31));
+                    accept_match(idxA, idxB);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+
+    for (int kb = 0; wave + 4 * kb < A.n_nodes; kb += 64) {
+        // 64 of this wave's nodes, one per lane: the common-node lookup (lower_bound walk of :248-352) runs in parallel
+        const int ia = wave + 4 * (kb + lane);
+        uint32_t nA = 0, nB = 0, offA = 0, offB = 0;
+        if (ia < A.n_nodes) {
+            const uint32_t node_id = A.fv_node[ia];
+            const int guess = min(ia, B.n_nodes - 1);        // two keyframes usually populate the same nodes: same index
+            const int ib = (guess >= 0 && B.fv_node[guess] == node_id) ? guess : find_node(B.fv_node, B.n_nodes, node_id);
+            if (ib >= 0) {
+                offA = A.fv_off[ia]; nA = A.fv_off[ia + 1] - offA;
+                offB = B.fv_off[ib]; nB = B.fv_off[ib + 1] - offB;
+                if (nB == 0) nA = 0;
+            }
+        }
+        unsigned long long todo = __ballot(nA != 0);
+        // nodes too large for the record format: the generic loop, first
+        for (unsigned long long big = __ballot(nA > REC_MAX_Q || nB > REC_MAX_T); big; big &= big - 1) {
+            const int node = __builtin_ctzll(big);
+            todo &= ~(1ull << node);
+            generic_node((uint32_t)__builtin_amdgcn_readlane((int)offA, node), (uint32_t)__builtin_amdgcn_readlane((int)nA, node),
+                         (uint32_t)__builtin_amdgcn_readlane((int)offB, node), (uint32_t)__builtin_amdgcn_readlane((int)nB, node));
+        }
+        // ---- the 32 x 32 tiles of the remaining nodes, one after the other; the operands of the NEXT tile (two 16-byte
+        // loads per lane) are requested before the current one is multiplied.  All of this state is wave-uniform.
+        struct TileDesc { uint32_t nA, nB, offA, offB, qa0, cb0; bool first, last; };
+        uint32_t s_nA = 0, s_nB = 0, s_offA = 0, s_offB = 0, s_qa0 = 0, s_cb0 = 0;
+        bool in_node = false;
+        auto fetch = [&](TileDesc &d) -> bool {
+            if (in_node) {
+                s_cb0 += 32;
+                if (s_cb0 >= s_nB) { s_cb0 = 0; s_qa0 += 32; if (s_qa0 >= s_nA) in_node = false; }
+            }
+            if (!in_node) {
+                if (!todo) return false;
+                const int node = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                s_nA = (uint32_t)__builtin_amdgcn_readlane((int)nA, node); s_nB = (uint32_t)__builtin_amdgcn_readlane((int)nB, node);
+                s_offA = (uint32_t)__builtin_amdgcn_readlane((int)offA, node); s_offB = (uint32_t)__builtin_amdgcn_readlane((int)offB, node);
+                s_qa0 = 0; s_cb0 = 0; in_node = true;
+            }
+            d.nA = s_nA; d.nB = s_nB; d.offA = s_offA; d.offB = s_offB; d.qa0 = s_qa0; d.cb0 = s_cb0;
+            d.first = s_qa0 == 0 && s_cb0 == 0;
+            d.last = s_qa0 + 32 >= s_nA && s_cb0 + 32 >= s_nB;
+            return true;
+        };
+        // lane (col, h) takes 16-byte half h of row col: dword s of it feeds k step s, for queries and candidates alike (the
+        // order of the 256 bit positions inside the product is free as long as both operands use the same one)
+        auto request = [&](const TileDesc &d, v4u &xq, v4u &xc) {
+            xq = rowsA[2 * (size_t)(d.offA + d.qa0 + (uint32_t)col) + h];
+            xc = rowsB[2 * (size_t)(d.offB + d.cb0 + (uint32_t)col) + h];
+        };
+        TileDesc ND;
+        v4u nxq = {0, 0, 0, 0}, nxc = {0, 0, 0, 0};
+        bool have = fetch(ND);
+        if (have) request(ND, nxq, nxc);
+        while (have) {
+            const TileDesc D = ND;
+            const v4u xq = nxq, xc = nxc;
+            have = fetch(ND);
+            if (have) request(ND, nxq, nxc);
+            const uint32_t nAs = D.nA, nBs = D.nB, offAs = D.offA, offBs = D.offB, qa0 = D.qa0, cb0 = D.cb0;
+            if (D.first) {
+                if (lane == 0) *cnt = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                v16f acc = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const uint32_t wq[4] = {xq.x, xq.y, xq.z, xq.w}, wc[4] = {xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s]), expand_fp4(wq[s]), acc, 4, 4, 0, one, 0, one);
+                float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+                m = fmaxf(m, acc[15]);
+                if (qa0 + (uint32_t)col >= nAs) m = Tf;          // a row of the next node: not a query of this one
+                if (__any(m > Tf)) {
+                    // the lane holds query qa0 + col against candidates cb0 + (r & 3) + 8 (r >> 2) + 4 h
+                    const uint32_t q = qa0 + (uint32_t)col;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t t = cb0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);
+                        if (acc[r] > Tf && t < nBs && q < nAs) {
+                            const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
+                            const int pos = atomicAdd(cnt, 1);
+                            if (pos < BM_LIST) list[pos] = (q << 20) | (d << 13) | t;
+                        }
+                    }
+                }
+            }
+            if (!D.last) continue;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int R = __builtin_amdgcn_readfirstlane(*cnt);
+            if (R == 0) continue;
+            if (R > 64) { generic_node(offAs, nAs, offBs, nBs); continue; }
+            // ---- the claims, on the records alone: one record per lane
+            uint32_t rec = 0xFFFFFFFFu;
+            int idxA = 0, idxB = 0;
+            bool valid = false;
+            if (lane < R) {
+                rec = list[lane];
+                idxA = (int)A.fv_idx[offAs + (rec >> 20)];
+                idxB = (int)B.fv_idx[offBs + (rec & 0x1FFFu)];
+                const uint32_t fA = A.mp_flags[idxA];
+                valid = (fA & ORBM_MP_PRESENT) && !(fA & ORBM_MP_BAD);                      // :263-267 / :746-749
+                if (MODE == 1) {
+                    const uint32_t fB = B.mp_flags[idxB];
+                    valid = valid && (fB & ORBM_MP_PRESENT) && !(fB & ORBM_MP_BAD);          // :766-770
+                }
+            }
+            const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu, rk = rec & 0xFFFFFu;         // rk = d << 13 | t: the scan's ranking
+            const int rd = (int)((rec >> 13) & 0x7Fu);
+            unsigned long long vmask = __ballot(valid);
+            if (!vmask) continue;
+            bool shared = false;                               // another valid record with my query or my candidate?
+            {
+                unsigned long long it = vmask;
+                while (it) {
+                    const int i = __builtin_ctzll(it);
+                    it &= it - 1;
+                    const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane((int)rq, i), ot = (uint32_t)__builtin_amdgcn_readlane((int)rt, i);
+                    shared = shared || (lane != i && (oq == rq || ot == rt));
+                }
+            }
+            if (!__any(valid && shared)) {
+                // every query has one relevant candidate and nobody else wants it: best = that one, second best >= capd
+                if (valid && rd <= thr) accept_match(idxA, idxB);
+                continue;
+            }
+            // queries in the reference's order; a claim takes the candidate away from the later ones
+            bool active = valid, gone = false;
+            while (true) {
+                const uint32_t cq = wave_min_u32(active ? rq : 0xFFFFFFFFu);
+                if (cq == 0xFFFFFFFFu) break;
+                const bool mine = active && rq == cq;
+                const uint32_t k = (mine && !gone) ? rk : 0xFFFFFFFFu;
+                const uint32_t b = wave_min_u32(k);
+                const uint32_t s2 = wave_min_u32(k == b ? 0xFFFFFFFFu : k);               // (d, t) pairs of one query are distinct
+                if (b != 0xFFFFFFFFu) {
+                    const int bd = (int)(b >> 13);
+                    const bool second_passes = s2 == 0xFFFFFFFFu || (float)bd < __fmul_rn(ratio, (float)(int)(s2 >> 13));
+                    if (bd <= thr && second_passes) {                                      // :304-308 / :792-796
+                        const uint32_t tstar = b & 0x1FFFu;
+                        if (k == b) accept_match(idxA, idxB);
+                        if (valid && rt == tstar) gone = true;                             // :312 / :799
+                    }
+                }
+                active = active && !mine;
+            }
+        }
+    }
+    if (my_matches) atomicAdd(&nmatches, my_matches);
+    __syncthreads();
+    if (check_ori) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        int removed = 0;
+        for (int i = tid; i < nOut; i += 256) {
+            const int m = match[i];
+            if (m < 0) continue;
+            const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
+            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+            if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }        // :368-381 / :836-849
+        }
+        if (removed) atomicSub(&nmatches, removed);
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = nmatches;
+}
+
+}  // namespace
+
+// smallest distance that passes the ratio test as second best for every acceptable best distance (see the header comment);
+// never below TH_LOW + 1, so that every acceptable best distance is "relevant" too
+int orbm_bow_cap(float ratio) {
+    if (!(ratio > 0.f)) return 257;
+    int c = ORBM_TH_LOW + 1;
+    while (c <= 256 && !((float)c * ratio > (float)ORBM_TH_LOW)) c++;
+    return c;
+}
+
+int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
+                     int check_ori, int stride, int32_t *dm, int32_t *dc) {
+    if (mode == 0)
+        hipLaunchKernelGGL((bowm_kernel<0>), dim3(n_pairs), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, dfb, ratio, capd, check_ori, stride, dm, dc);
+    else
+        hipLaunchKernelGGL((bowm_kernel<1>), dim3(n_pairs), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, dfb, ratio, capd, check_ori, stride, dm, dc);
+    HIPCHK(ctx, hipGetLastError());
+    return ORBM_OK;
+}

@@ -481,8 +481,8 @@ int orbm_frames_upload(orbm_ctx *ctx, int n_frames, const orbm_frame_view *views
             f.sigma2[l] = l < v.n_levels ? v.level_sigma2[l] : 0.f;
         }
         int32_t id;
-        if (!ctx->free_frames.empty()) { id = ctx->free_frames.back(); ctx->free_frames.pop_back(); ctx->h_frames[id] = f; ctx->frame_arena[id] = arena_id; ctx->frame_arena8[id] = -1; ctx->frame_arena4[id] = -1; }
-        else { id = (int32_t)ctx->h_frames.size(); ctx->h_frames.push_back(f); ctx->frame_arena.push_back(arena_id); ctx->frame_arena8.push_back(-1); ctx->frame_arena4.push_back(-1); }
+        if (!ctx->free_frames.empty()) { id = ctx->free_frames.back(); ctx->free_frames.pop_back(); ctx->h_frames[id] = f; ctx->frame_arena[id] = arena_id; ctx->frame_arena8[id] = -1; ctx->frame_arena4[id] = -1; ctx->frame_arena4f[id] = -1; }
+        else { id = (int32_t)ctx->h_frames.size(); ctx->h_frames.push_back(f); ctx->frame_arena.push_back(arena_id); ctx->frame_arena8.push_back(-1); ctx->frame_arena4.push_back(-1); ctx->frame_arena4f.push_back(-1); }
         out_ids[k] = id;
         lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
     }
@@ -533,6 +533,8 @@ int orbm_frames_free(orbm_ctx *ctx, int n_frames, const int32_t *ids) {
         ctx->frame_arena8[id] = -1;
         arena_unref(ctx, ctx->frame_arena4[id]);
         ctx->frame_arena4[id] = -1;
+        arena_unref(ctx, ctx->frame_arena4f[id]);
+        ctx->frame_arena4f[id] = -1;
         ctx->free_frames.push_back(id);
     }
     return ORBM_OK;
@@ -751,10 +753,32 @@ __global__ __launch_bounds__(256) void expand_image_kernel(FrameDev *__restrict_
     ((gptr<v4u>)(BITS == 8 ? F.desc8 : F.desc4))[(size_t)row * CHUNKS + chunk] = out;
 }
 
+// The descriptor rows in FeatureVector order (FrameDev::descfv).  thread = one 16-byte half of one row; the rows from the
+// FeatureVector's length up to the padded end are zero.
+__global__ __launch_bounds__(256) void expand_image_fv_kernel(FrameDev *__restrict__ table, const int32_t *__restrict__ ids, int blocks_per_frame) {
+    const int f = blockIdx.x / blocks_per_frame;
+    const FrameG F(table[ids[f]]);
+    const int row = (blockIdx.x - f * blocks_per_frame) * 128 + (int)(threadIdx.x >> 1), half = threadIdx.x & 1;
+    const int rows = ((F.n + 31) & ~31) + 32;
+    if (row >= rows) return;
+    const int nfv = F.n_nodes > 0 ? (int)F.fv_off[F.n_nodes] : 0;
+    v4u out = {0, 0, 0, 0};
+    if (row < nfv) out = ((gptr<const v4u>)F.desc)[2 * (size_t)F.fv_idx[row] + half];
+    ((gptr<v4u>)F.descfv)[2 * (size_t)row + half] = out;
+}
+
+void orbm_drop_fv_image(orbm_ctx *ctx, int32_t id) {
+    if (id < 0 || (size_t)id >= ctx->h_frames.size() || !ctx->h_frames[id].descfv) return;
+    ctx->h_frames[id].descfv = nullptr;
+    arena_unref(ctx, ctx->frame_arena4f[id]);
+    ctx->frame_arena4f[id] = -1;
+}
+
 int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
-    std::vector<int> &slot_arena = bits == 8 ? ctx->frame_arena8 : ctx->frame_arena4;
-    auto image_of = [bits](FrameDev &f) -> const uint32_t *& { return bits == 8 ? f.desc8 : f.desc4; };
-    const size_t row_bytes = bits == 8 ? 256 : 128;
+    std::vector<int> &slot_arena = bits == 8 ? ctx->frame_arena8 : bits == 4 ? ctx->frame_arena4 : ctx->frame_arena4f;
+    auto image_of = [bits](FrameDev &f) -> const uint32_t *& { return bits == 8 ? f.desc8 : bits == 4 ? f.desc4 : f.descfv; };
+    const size_t row_bytes = bits == 8 ? 256 : bits == 4 ? 128 : 32;
+    const int extra_rows = bits == 5 ? 32 : 0;         // descfv: a 32-row tile that starts at a node's last rows reads on
     std::vector<int32_t> need;
     if (ids) {
         for (int i = 0; i < n; i++) {
@@ -773,7 +797,7 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
     int max_n8 = 32;
     std::vector<size_t> off(need.size());
     for (size_t k = 0; k < need.size(); k++) {
-        const int n8 = std::max(32, (ctx->h_frames[need[k]].n + 31) & ~31);
+        const int n8 = std::max(32, (ctx->h_frames[need[k]].n + 31) & ~31) + extra_rows;
         off[k] = total; total += (size_t)n8 * row_bytes;
         max_n8 = std::max(max_n8, n8);
     }
@@ -803,7 +827,10 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
         HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, tab_bytes, hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(ctx->ws, need.data(), id_bytes, hipMemcpyHostToDevice));
     }
-    if (bits == 8) {
+    if (bits == 5) {
+        const int bpf = (max_n8 + 127) / 128;
+        hipLaunchKernelGGL(expand_image_fv_kernel, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+    } else if (bits == 8) {
         const int bpf = max_n8 / 16;
         hipLaunchKernelGGL(expand_image_kernel<8>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
     } else {

@@ -31,6 +31,10 @@ struct FrameDev {
     const uint32_t *desc8;
     // the same as FP4 (E2M1) values, two per byte: +1.0 = 0x2, -1.0 = 0xA; 128 B per row (operands of the MX-scaled MFMA form)
     const uint32_t *desc4;
+    // the descriptors again (32-byte rows) in FeatureVector order: row j = keypoint fv_idx[j], so a vocabulary node's rows are
+    // consecutive and 32 more zero rows follow the last one.  Operand image of the matrix-core form of the BoW searches
+    // (bowm.hip); built on first use, dropped when the FeatureVector is rebuilt.
+    const uint32_t *descfv;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     float sf[ORBM_MAX_LEVELS];
     float sigma2[ORBM_MAX_LEVELS];
@@ -85,6 +89,7 @@ struct orbm_ctx {
     std::vector<int> frame_arena;      // arena index per slot, -1 = free slot
     std::vector<int> frame_arena8;     // arena of the slot's desc8 image, -1 = none
     std::vector<int> frame_arena4;     // arena of the slot's desc4 image, -1 = none
+    std::vector<int> frame_arena4f;    // arena of the slot's descfv image, -1 = none
     std::vector<int32_t> free_frames;
     FrameDev *d_frames = nullptr;
     size_t d_frames_cap = 0;
@@ -137,11 +142,15 @@ int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
 void *orbm_pin_up(orbm_ctx *ctx, size_t bytes);      // pinned upload staging of at least `bytes`, or null (too large / failed)
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
 int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
-int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // bits = 8 (desc8) or 4 (desc4); ids == nullptr: every live frame
+int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // bits = 8 (desc8), 4 (desc4) or 5 (descfv, raw rows in FeatureVector order); ids == nullptr: every live frame
+void orbm_drop_fv_image(orbm_ctx *ctx, int32_t id);                          // host side of "the FeatureVector of frame id was rebuilt" (the device entry is cleared by the rebuilding kernel)
 int orbm_bvecs_reserve(orbm_ctx *ctx, int n_vecs, const int32_t *cap, const int32_t *n_init, int32_t *out_ids, void **arena_base,
                        std::vector<size_t> &o_word, std::vector<size_t> &o_val, size_t *total_bytes);   // bowscore.hip
 int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const char *what);
 extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx);
+int orbm_bow_cap(float ratio);                        // bowm.hip: distances below it are the only ones that can change a SearchByBoW result
+int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
+                     int check_ori, int stride, int32_t *dm, int32_t *dc);   // bowm.hip: MFMA form, one workgroup per pair
 int orbm_bow_scratch_resolve(orbm_ctx *ctx);         // bow.hip: device address of the static scratch array of ctx->device (orbm_create calls it)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more
@@ -202,7 +211,7 @@ struct FrameG {
     gptr<uint32_t> cell_off, cell_idx;
     gptr<const v4f> cell_rec;
     gptr<uint16_t> cell_nxt;
-    gptr<const uint32_t> fv_node, fv_off, fv_idx, desc8, desc4;
+    gptr<const uint32_t> fv_node, fv_off, fv_idx, desc8, desc4, descfv;
     float min_x, min_y, max_x, max_y, inv_w, inv_h;
     gptr<const float> sf, sigma2;
     FrameG() = default;
@@ -211,7 +220,7 @@ struct FrameG {
           angle(in_global(f.angle)), angle_raw(in_global(f.angle_raw)), uright(in_global(f.uright)), octave(in_global(f.octave)),
           mp_flags(in_global(f.mp_flags)), cell_off(in_global(f.cell_off)), cell_idx(in_global(f.cell_idx)),
           cell_rec((gptr<const v4f>)f.cell_rec), cell_nxt(in_global(f.cell_nxt)), fv_node(in_global(f.fv_node)),
-          fv_off(in_global(f.fv_off)), fv_idx(in_global(f.fv_idx)), desc8(in_global(f.desc8)), desc4(in_global(f.desc4)),
+          fv_off(in_global(f.fv_off)), fv_idx(in_global(f.fv_idx)), desc8(in_global(f.desc8)), desc4(in_global(f.desc4)), descfv(in_global(f.descfv)),
           min_x(f.min_x), min_y(f.min_y), max_x(f.max_x), max_y(f.max_y), inv_w(f.inv_w), inv_h(f.inv_h),
           sf(in_global(&f.sf[0])), sigma2(in_global(&f.sigma2[0])) {}
 };

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(FVB_THREADS) void fv_build_kernel(FrameDev *__restr
         fv_idx[p] = (uint32_t)kp;
         if (p == 0 || (kp >> 32) != (keys[p - 1] >> 32)) { fv_node[base] = (uint32_t)(kp >> 32); fv_off[base] = (uint32_t)p; base++; }
     }
-    if (tid == 0) { fv_off[total] = (uint32_t)n; F.n_nodes = (int32_t)total; n_nodes_out[f] = (int32_t)total; }
+    // the FeatureVector-ordered operand image (descfv), if one was built, describes the old order: dropped (the host side
+    // does the same to its mirror and releases the memory, orbm_drop_fv_image)
+    if (tid == 0) { fv_off[total] = (uint32_t)n; F.n_nodes = (int32_t)total; F.descfv = nullptr; n_nodes_out[f] = (int32_t)total; }
 }
 
 // BowVector of each frame (TemplatedVocabulary::transform, BowVector part): words ascending; value = the weights of the
@@ -450,7 +452,7 @@ extern "C" int orbm_frames_compute_bow(orbm_ctx *ctx, int32_t vocab_id, int n_fr
     rc = io.finish();
     if (rc) return rc;
     // keep the host mirrors of the tables in step (they are re-sent when a table grows)
-    for (int k = 0; k < n_frames; k++) ctx->h_frames[frames[k]].n_nodes = nn[k];
+    for (int k = 0; k < n_frames; k++) { ctx->h_frames[frames[k]].n_nodes = nn[k]; orbm_drop_fv_image(ctx, frames[k]); }
     if (bowvec_ids) for (int k = 0; k < n_frames; k++) ctx->h_bvecs[bowvec_ids[k]].n = nw[k];
     return ORBM_OK;
 }

@@ -20,7 +20,7 @@ mixes = {"bench mix": bench.pair_list(np.random.default_rng(3), ids, P),
 match = torch.empty((P, bench.N_FEAT), dtype=torch.int32, device=dev); counts = torch.empty(P, dtype=torch.int32, device=dev)
 from orbslam2_amd import _lib
 L = _lib.load()
-for form in (2,):
+for form in (0, 2):
   L.orbm__bow_variant(form)
   for variant in (1, 0):
     for name, (fa, fb) in mixes.items():

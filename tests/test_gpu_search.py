@@ -93,10 +93,10 @@ def test_triang_large_batch(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [1, 2, 5])
 def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
-    """The BoW searches exist in two forms (candidates on lanes / queries on lanes; the library picks by batch size):
-    both give the reference's result on every kind of input, for small and large batches."""
+    """The BoW searches exist in three forms (candidates on lanes / queries on lanes / node blocks on the matrix cores; the
+    library picks by batch size): all give the reference's result on every kind of input, for small and large batches."""
     from orbslam2_amd import _lib
     L = _lib.load()
     try:
@@ -133,6 +133,32 @@ def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
     finally:
         L.orbm__bow_variant(0)
         L.orbm__bow_split_below(2048)
+
+
+@pytest.mark.parametrize("ratio", [0.3, 0.6, 0.9, 1.0, 1.5])
+def test_bow_matrix_core_form_ratios(ctx, orc, ratio):
+    """The matrix-core form only looks at distances below a bound derived from the ratio (67 for 0.75, 84 for 0.6, 51 for
+    ratios of 1 and more; above 128, as for 0.3, the library takes the vector-ALU form): every ratio gives the reference's
+    result, on overlapping keyframes and on keyframes whose queries fight over candidates."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    kfs = synth.keyframe_pool(seed=synth.SEED0 + 34, n_kf=3, n=1500) + contended_pool(51, 3, 600, 120) + contended_pool(61, 2, 500, 400, p_flip=0.12)
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.meshgrid(np.arange(len(kfs)), np.arange(len(kfs)))
+    pa, pb = pa.ravel(), pb.ravel()
+    try:
+        L.orbm__bow_variant(5)
+        for variant in (0, 1):
+            counts, match = ctx.search_bow(variant, ids[pa], ids[pb], ratio, True, stride=1500)
+            tot = 0
+            for k, (i, j) in enumerate(zip(pa, pb)):
+                wc, wm, _ = orc.search_bow(variant, kfs[i], kfs[j], ratio, True)
+                assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (ratio, variant, i, j, counts[k], wc)
+                tot += wc
+            assert tot > 500
+    finally:
+        L.orbm__bow_variant(0)
+    ctx.free_frames(ids)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
