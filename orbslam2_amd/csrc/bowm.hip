@@ -36,7 +36,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
-constexpr int BM_LIST = 128;          // records a wave can hold per node (more than 64 -> generic loop)
+constexpr int BM_LIST = 320;          // records a wave collects before it settles them (a node with more than 64 takes the generic loop)
 constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
 
 __device__ __forceinline__ void load_row(gptr<const uint32_t> desc, int idx, uint32_t (&r)[8]) {
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                                                    int32_t *__restrict__ match_all, int32_t *__restrict__ counts) {
     __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint32_t s_list[4][BM_LIST];
+    __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
     __shared__ int s_cnt[4];
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     const int one = 0x7F7F7F7F;                                        // E8M0 block scale 2^0 in every byte
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
     uint32_t *list = s_list[wave];
+    uint8_t *tags = s_tags[wave];
     int *cnt = &s_cnt[wave];
     int my_matches = 0;
 
@@ -176,8 +178,9 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         }
         // ---- the 32 x 32 tiles of the remaining nodes, one after the other; the operands of the NEXT tile (two 16-byte
         // loads per lane) are requested before the current one is multiplied.  All of this state is wave-uniform.
-        struct TileDesc { uint32_t nA, nB, offA, offB, qa0, cb0; bool first, last; };
+        struct TileDesc { uint32_t nA, nB, offA, offB, qa0, cb0; int node; bool last; };
         uint32_t s_nA = 0, s_nB = 0, s_offA = 0, s_offB = 0, s_qa0 = 0, s_cb0 = 0;
+        int s_node = 0;
         bool in_node = false;
         auto fetch = [&](TileDesc &d) -> bool {
             if (in_node) {
@@ -186,14 +189,13 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             }
             if (!in_node) {
                 if (!todo) return false;
-                const int node = __builtin_ctzll(todo);
+                s_node = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                s_nA = (uint32_t)__builtin_amdgcn_readlane((int)nA, node); s_nB = (uint32_t)__builtin_amdgcn_readlane((int)nB, node);
-                s_offA = (uint32_t)__builtin_amdgcn_readlane((int)offA, node); s_offB = (uint32_t)__builtin_amdgcn_readlane((int)offB, node);
+                s_nA = (uint32_t)__builtin_amdgcn_readlane((int)nA, s_node); s_nB = (uint32_t)__builtin_amdgcn_readlane((int)nB, s_node);
+                s_offA = (uint32_t)__builtin_amdgcn_readlane((int)offA, s_node); s_offB = (uint32_t)__builtin_amdgcn_readlane((int)offB, s_node);
                 s_qa0 = 0; s_cb0 = 0; in_node = true;
             }
-            d.nA = s_nA; d.nB = s_nB; d.offA = s_offA; d.offB = s_offB; d.qa0 = s_qa0; d.cb0 = s_cb0;
-            d.first = s_qa0 == 0 && s_cb0 == 0;
+            d.nA = s_nA; d.nB = s_nB; d.offA = s_offA; d.offB = s_offB; d.qa0 = s_qa0; d.cb0 = s_cb0; d.node = s_node;
             d.last = s_qa0 + 32 >= s_nA && s_cb0 + 32 >= s_nB;
             return true;
         };
@@ -203,21 +205,106 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             xq = rowsA[2 * (size_t)(d.offA + d.qa0 + (uint32_t)col) + h];
             xc = rowsB[2 * (size_t)(d.offB + d.cb0 + (uint32_t)col) + h];
         };
+
+        // ---- the claims, on the records alone.  Records wait in the wave's list (a node's records are consecutive there)
+        // and are settled many nodes at a time, one record per lane: the dependent loads behind a record (keypoint
+        // indices, map-point flags, angles) are then paid once per 64 records, not once per node.
+        auto resolve = [&](int total) {
+            int start = 0;
+            while (start < total) {
+                int take = min(64, total - start);
+                uint32_t rec = 0xFFFFFFFFu;
+                int tg = -1;
+                if (lane < take) { rec = list[start + lane]; tg = (int)tags[start + lane]; }
+                if (start + 64 < total) {                         // never split a node between two rounds (a node has <= 64 records)
+                    const int next_tag = (int)tags[start + 64], last_tag = __builtin_amdgcn_readlane(tg, 63);
+                    if (next_tag == last_tag) take = __builtin_ctzll(__ballot(tg == last_tag));
+                }
+                const bool in = lane < take;
+                const int src = in ? tg : 0;
+                const uint32_t nOffA = (uint32_t)__shfl((int)offA, src, 64), nOffB = (uint32_t)__shfl((int)offB, src, 64);
+                const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu, rk = rec & 0xFFFFFu;     // rk = d << 13 | t: the scan's ranking
+                const int rd = (int)((rec >> 13) & 0x7Fu);
+                int idxA = 0, idxB = 0;
+                bool valid = false;
+                if (in) {
+                    idxA = (int)A.fv_idx[nOffA + rq];
+                    idxB = (int)B.fv_idx[nOffB + rt];
+                    const uint32_t fA = A.mp_flags[idxA];
+                    valid = (fA & ORBM_MP_PRESENT) && !(fA & ORBM_MP_BAD);                  // :263-267 / :746-749
+                    if (MODE == 1) {
+                        const uint32_t fB = B.mp_flags[idxB];
+                        valid = valid && (fB & ORBM_MP_PRESENT) && !(fB & ORBM_MP_BAD);      // :766-770
+                    }
+                }
+                start += take;
+                const unsigned long long vmask = __ballot(valid);
+                if (!vmask) continue;
+                // the lanes of my node: [first, last]
+                const int prev_tg = __shfl_up(tg, 1, 64);
+                const unsigned long long heads = __ballot(in && (lane == 0 || tg != prev_tg));
+                const int first = 63 - __builtin_clzll((heads & (~0ull >> (63 - lane))) | 1ull);
+                const unsigned long long later = lane < 63 ? (heads | (take < 64 ? 1ull << take : 0ull)) >> (lane + 1) : 0ull;
+                const int last = later ? lane + __builtin_ctzll(later) : take - 1;
+                const int run = last - first + 1;
+                // does another valid record of my node name my query or my candidate?  (cyclic walk over the node's lanes)
+                int max_run = in ? run : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) max_run = max(max_run, __shfl_xor(max_run, off, 64));
+                max_run = __builtin_amdgcn_readfirstlane(max_run);
+                const uint32_t packed = (rq << 13) | rt | (valid ? 1u << 31 : 0u);
+                bool shared = false;
+                for (int dlt = 1; dlt < max_run; dlt++) {
+                    int partner = lane + dlt;
+                    if (partner > last) partner = first + (partner - last - 1) % max(run, 1);
+                    const uint32_t o = (uint32_t)__shfl((int)packed, in ? partner : lane, 64);
+                    if (in && partner != lane && (o >> 31) && (((o >> 13) & 0xFFFu) == rq || (o & 0x1FFFu) == rt)) shared = true;
+                }
+                const unsigned long long smask = __ballot(valid && shared);
+                const unsigned long long mine_mask = run >= 64 ? ~0ull : ((1ull << run) - 1ull) << first;
+                const bool contested_node = in && (smask & mine_mask) != 0ull;
+                // a node where every query has one relevant candidate that nobody else wants: best = that one, second best >= capd
+                if (valid && !contested_node && rd <= thr) accept_match(idxA, idxB);
+                if (!smask) continue;
+                // the other nodes: queries in the reference's order; a claim takes the candidate away from the later ones
+                bool active = valid && contested_node, gone = false;
+                const uint32_t okey = ((uint32_t)tg << 12) | rq;                            // (node, query position)
+                while (true) {
+                    const uint32_t cq = wave_min_u32(active ? okey : 0xFFFFFFFFu);
+                    if (cq == 0xFFFFFFFFu) break;
+                    const bool mine = active && okey == cq;
+                    const uint32_t k = (mine && !gone) ? rk : 0xFFFFFFFFu;
+                    const uint32_t b = wave_min_u32(k);
+                    const uint32_t s2 = wave_min_u32(k == b ? 0xFFFFFFFFu : k);           // (d, t) pairs of one query are distinct
+                    if (b != 0xFFFFFFFFu) {
+                        const int bd = (int)(b >> 13);
+                        const bool second_passes = s2 == 0xFFFFFFFFu || (float)bd < __fmul_rn(ratio, (float)(int)(s2 >> 13));
+                        if (bd <= thr && second_passes) {                                  // :304-308 / :792-796
+                            const uint32_t tstar = b & 0x1FFFu;
+                            const int node_star = (int)(cq >> 12);
+                            if (k == b) accept_match(idxA, idxB);
+                            if (valid && tg == node_star && rt == tstar) gone = true;      // :312 / :799
+                        }
+                    }
+                    active = active && !mine;
+                }
+            }
+        };
+
         TileDesc ND;
         v4u nxq = {0, 0, 0, 0}, nxc = {0, 0, 0, 0};
         bool have = fetch(ND);
         if (have) request(ND, nxq, nxc);
+        int node_start = 0;                                   // records of finished nodes waiting in the list
+        if (lane == 0) *cnt = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         while (have) {
             const TileDesc D = ND;
             const v4u xq = nxq, xc = nxc;
             have = fetch(ND);
             if (have) request(ND, nxq, nxc);
-            const uint32_t nAs = D.nA, nBs = D.nB, offAs = D.offA, offBs = D.offB, qa0 = D.qa0, cb0 = D.cb0;
-            if (D.first) {
-                if (lane == 0) *cnt = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            const uint32_t nAs = D.nA, nBs = D.nB, qa0 = D.qa0, cb0 = D.cb0;
             {
                 v16f acc = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 const uint32_t wq[4] = {xq.x, xq.y, xq.z, xq.w}, wc[4] = {xc.x, xc.y, xc.z, xc.w};
@@ -237,7 +324,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                         if (acc[r] > Tf && t < nBs && q < nAs) {
                             const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
                             const int pos = atomicAdd(cnt, 1);
-                            if (pos < BM_LIST) list[pos] = (q << 20) | (d << 13) | t;
+                            if (pos < BM_LIST) { list[pos] = (q << 20) | (d << 13) | t; tags[pos] = (uint8_t)D.node; }
                         }
                     }
                 }
@@ -245,64 +332,25 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             if (!D.last) continue;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int R = __builtin_amdgcn_readfirstlane(*cnt);
-            if (R == 0) continue;
-            if (R > 64) { generic_node(offAs, nAs, offBs, nBs); continue; }
-            // ---- the claims, on the records alone: one record per lane
-            uint32_t rec = 0xFFFFFFFFu;
-            int idxA = 0, idxB = 0;
-            bool valid = false;
-            if (lane < R) {
-                rec = list[lane];
-                idxA = (int)A.fv_idx[offAs + (rec >> 20)];
-                idxB = (int)B.fv_idx[offBs + (rec & 0x1FFFu)];
-                const uint32_t fA = A.mp_flags[idxA];
-                valid = (fA & ORBM_MP_PRESENT) && !(fA & ORBM_MP_BAD);                      // :263-267 / :746-749
-                if (MODE == 1) {
-                    const uint32_t fB = B.mp_flags[idxB];
-                    valid = valid && (fB & ORBM_MP_PRESENT) && !(fB & ORBM_MP_BAD);          // :766-770
-                }
+            const int have_now = __builtin_amdgcn_readfirstlane(*cnt);
+            if (have_now - node_start > 64) {
+                // more relevant pairs than lanes: this node takes the generic loop, its records are dropped
+                generic_node(D.offA, nAs, D.offB, nBs);
+                if (lane == 0) *cnt = node_start;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                node_start = have_now;
             }
-            const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu, rk = rec & 0xFFFFFu;         // rk = d << 13 | t: the scan's ranking
-            const int rd = (int)((rec >> 13) & 0x7Fu);
-            unsigned long long vmask = __ballot(valid);
-            if (!vmask) continue;
-            bool shared = false;                               // another valid record with my query or my candidate?
-            {
-                unsigned long long it = vmask;
-                while (it) {
-                    const int i = __builtin_ctzll(it);
-                    it &= it - 1;
-                    const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane((int)rq, i), ot = (uint32_t)__builtin_amdgcn_readlane((int)rt, i);
-                    shared = shared || (lane != i && (oq == rq || ot == rt));
-                }
-            }
-            if (!__any(valid && shared)) {
-                // every query has one relevant candidate and nobody else wants it: best = that one, second best >= capd
-                if (valid && rd <= thr) accept_match(idxA, idxB);
-                continue;
-            }
-            // queries in the reference's order; a claim takes the candidate away from the later ones
-            bool active = valid, gone = false;
-            while (true) {
-                const uint32_t cq = wave_min_u32(active ? rq : 0xFFFFFFFFu);
-                if (cq == 0xFFFFFFFFu) break;
-                const bool mine = active && rq == cq;
-                const uint32_t k = (mine && !gone) ? rk : 0xFFFFFFFFu;
-                const uint32_t b = wave_min_u32(k);
-                const uint32_t s2 = wave_min_u32(k == b ? 0xFFFFFFFFu : k);               // (d, t) pairs of one query are distinct
-                if (b != 0xFFFFFFFFu) {
-                    const int bd = (int)(b >> 13);
-                    const bool second_passes = s2 == 0xFFFFFFFFu || (float)bd < __fmul_rn(ratio, (float)(int)(s2 >> 13));
-                    if (bd <= thr && second_passes) {                                      // :304-308 / :792-796
-                        const uint32_t tstar = b & 0x1FFFu;
-                        if (k == b) accept_match(idxA, idxB);
-                        if (valid && rt == tstar) gone = true;                             // :312 / :799
-                    }
-                }
-                active = active && !mine;
+            if (node_start > BM_LIST - 64) {                   // the next node may need 64 slots
+                resolve(node_start);
+                node_start = 0;
+                if (lane == 0) *cnt = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
+        resolve(node_start);                                  // before the lanes' node table moves on to the next 64 nodes
     }
     if (my_matches) atomicAdd(&nmatches, my_matches);
     __syncthreads();

@@ -11,13 +11,16 @@ import test_gpu_search as T
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+FORMS = tuple(int(x) for x in os.environ.get('ORBM_FUZZ_FORMS', '1,2,5').split(','))
+ONLY_BOW = os.environ.get('ORBM_FUZZ_ONLY_BOW') == '1'
 orc.lib()
 ctx = Context(0)
 t0 = time.time()
 for s in range(first, first + n_seeds):
     os.environ["ORBM_FUZZ_SEED"] = str(1000 * s)
-    T.test_claim_rounds_fuzz_near_thresholds(ctx, orc)
-    for form in (1, 2):
+    if not ONLY_BOW:
+        T.test_claim_rounds_fuzz_near_thresholds(ctx, orc)
+    for form in FORMS:
         T.test_bow_fuzz_near_thresholds(ctx, orc, form)
     print("seed offset %d ok (%.0f s)" % (1000 * s, time.time() - t0), flush=True)
 ctx.close()

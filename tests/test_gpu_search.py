@@ -595,9 +595,9 @@ def test_claim_rounds_fuzz_near_thresholds(ctx, orc):
         ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [1, 2, 5])
 def test_bow_fuzz_near_thresholds(ctx, orc, form):
-    """Both BoW kernel forms on crowded nodes whose distances straddle TH_LOW and the ratio test."""
+    """All BoW kernel forms on crowded nodes whose distances straddle TH_LOW and the ratio test."""
     from orbslam2_amd import _lib
     L = _lib.load()
     rng = np.random.default_rng(4242 + form + _fuzz_offset())
