@@ -71,10 +71,16 @@ __device__ __forceinline__ int find_node(gptr<const uint32_t> nodes, int n, uint
 }
 
 // 32 descriptor bits -> 32 FP4 values (+1.0 = 0x2 for a 0 bit, -1.0 = 0xA for a 1 bit), eight per dword: dword k takes bits
-// k, k + 4, ..., k + 28, which already sit at the nibble positions.  7 vector instructions.
-__device__ __forceinline__ v8i expand_fp4(uint32_t w) {
-    return (v8i){(int)(((w & 0x11111111u) << 3) | 0x22222222u), (int)(((w & 0x22222222u) << 2) | 0x22222222u),
-                 (int)(((w & 0x44444444u) << 1) | 0x22222222u), (int)((w & 0x88888888u) | 0x22222222u), 0, 0, 0, 0};
+// 3 - k, 7 - k, ..., 31 - k, shifted up to the sign position of their nibble.  7 vector instructions (3 shifts + 4
+// v_and_or_b32; written as asm because the compiler otherwise spends 11: shift, and, or).
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t bits) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
+    return r;
+}
+__device__ __forceinline__ v8i expand_fp4(uint32_t w, uint32_t ones) {
+    const uint32_t sign = 0x88888888u;
+    return (v8i){(int)and_or(w << 3, sign, ones), (int)and_or(w << 2, sign, ones), (int)and_or(w << 1, sign, ones), (int)and_or(w, sign, ones), 0, 0, 0, 0};
 }
 
 // MODE 0: a7 (KF -> F), 1: a8 (KF -> KF)
@@ -85,7 +91,6 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
-    __shared__ int s_cnt[4];
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
@@ -104,10 +109,11 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     const int thr = MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW;          // :304 / :792
     const float Tf = (float)(256 - 2 * capd);                          // dot > Tf  <=>  distance < capd
     const int one = 0x7F7F7F7F;                                        // E8M0 block scale 2^0 in every byte
+    uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
+    asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
     uint32_t *list = s_list[wave];
     uint8_t *tags = s_tags[wave];
-    int *cnt = &s_cnt[wave];
     int my_matches = 0;
 
     auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815
@@ -202,6 +208,8 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         // lane (col, h) takes 16-byte half h of row col: dword s of it feeds k step s, for queries and candidates alike (the
         // order of the 256 bit positions inside the product is free as long as both operands use the same one)
         auto request = [&](const TileDesc &d, v4u &xq, v4u &xc) {
+            // a tile that starts near a node's end reads on into the next node's rows (the image ends with 32 spare rows); they
+            // multiply as 0.0, see `live` below
             xq = rowsA[2 * (size_t)(d.offA + d.qa0 + (uint32_t)col) + h];
             xc = rowsB[2 * (size_t)(d.offB + d.cb0 + (uint32_t)col) + h];
         };
@@ -210,6 +218,8 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         // and are settled many nodes at a time, one record per lane: the dependent loads behind a record (keypoint
         // indices, map-point flags, angles) are then paid once per 64 records, not once per node.
         auto resolve = [&](int total) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the records were written by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
             int start = 0;
             while (start < total) {
                 int take = min(64, total - start);
@@ -223,11 +233,13 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 const bool in = lane < take;
                 const int src = in ? tg : 0;
                 const uint32_t nOffA = (uint32_t)__shfl((int)offA, src, 64), nOffB = (uint32_t)__shfl((int)offB, src, 64);
+                const uint32_t nNA = (uint32_t)__shfl((int)nA, src, 64), nNB = (uint32_t)__shfl((int)nB, src, 64);
                 const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu, rk = rec & 0xFFFFFu;     // rk = d << 13 | t: the scan's ranking
                 const int rd = (int)((rec >> 13) & 0x7Fu);
                 int idxA = 0, idxB = 0;
                 bool valid = false;
-                if (in) {
+                // (rows past a node's end cannot produce records; the bounds test only keeps a logic error from becoming a wild read)
+                if (in && rq < nNA && rt < nNB) {
                     idxA = (int)A.fv_idx[nOffA + rq];
                     idxB = (int)B.fv_idx[nOffB + rt];
                     const uint32_t fA = A.mp_flags[idxA];
@@ -295,10 +307,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         v4u nxq = {0, 0, 0, 0}, nxc = {0, 0, 0, 0};
         bool have = fetch(ND);
         if (have) request(ND, nxq, nxc);
-        int node_start = 0;                                   // records of finished nodes waiting in the list
-        if (lane == 0) *cnt = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        int node_start = 0, n_rec = 0;                        // records of finished nodes waiting in the list / records so far
         while (have) {
             const TileDesc D = ND;
             const v4u xq = nxq, xc = nxc;
@@ -308,46 +317,43 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             {
                 v16f acc = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 const uint32_t wq[4] = {xq.x, xq.y, xq.z, xq.w}, wc[4] = {xc.x, xc.y, xc.z, xc.w};
+                // a row past the node's end multiplies as 0.0 everywhere (not as the +1.0 its zero bits would expand to): its
+                // dots are 0 = distance 128, never below capd, so no record can name a row that does not exist
+                const uint32_t liveq = qa0 + (uint32_t)col < nAs ? ones : 0u, livec = cb0 + (uint32_t)col < nBs ? ones : 0u;
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s]), expand_fp4(wq[s]), acc, 4, 4, 0, one, 0, one);
+                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s], livec), expand_fp4(wq[s], liveq), acc, 4, 4, 0, one, 0, one);
                 float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
                 m = fmaxf(m, acc[15]);
-                if (qa0 + (uint32_t)col >= nAs) m = Tf;          // a row of the next node: not a query of this one
                 if (__any(m > Tf)) {
                     // the lane holds query qa0 + col against candidates cb0 + (r & 3) + 8 (r >> 2) + 4 h
-                    const uint32_t q = qa0 + (uint32_t)col;
+                    const uint32_t qbits = (qa0 + (uint32_t)col) << 20, t0 = cb0 + (uint32_t)(4 * h);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const uint32_t t = cb0 + (uint32_t)((r & 3) + 8 * (r >> 2) + 4 * h);
-                        if (acc[r] > Tf && t < nBs && q < nAs) {
+                        const bool hit = acc[r] > Tf;
+                        const unsigned long long hm = __ballot(hit);
+                        if (!hm) continue;
+                        if (hit) {
                             const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
-                            const int pos = atomicAdd(cnt, 1);
-                            if (pos < BM_LIST) { list[pos] = (q << 20) | (d << 13) | t; tags[pos] = (uint8_t)D.node; }
+                            const int pos = n_rec + (int)__popcll(hm & ((1ull << lane) - 1ull));   // the wave counts its own records
+                            if (pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + (uint32_t)((r & 3) + 8 * (r >> 2))); tags[pos] = (uint8_t)D.node; }
                         }
+                        n_rec += (int)__popcll(hm);
                     }
                 }
             }
             if (!D.last) continue;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int have_now = __builtin_amdgcn_readfirstlane(*cnt);
-            if (have_now - node_start > 64) {
+            if (n_rec - node_start > 64) {
                 // more relevant pairs than lanes: this node takes the generic loop, its records are dropped
                 generic_node(D.offA, nAs, D.offB, nBs);
-                if (lane == 0) *cnt = node_start;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                n_rec = node_start;
             } else {
-                node_start = have_now;
+                node_start = n_rec;
             }
             if (node_start > BM_LIST - 64) {                   // the next node may need 64 slots
                 resolve(node_start);
-                node_start = 0;
-                if (lane == 0) *cnt = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                node_start = 0; n_rec = 0;
             }
         }
         resolve(node_start);                                  // before the lanes' node table moves on to the next 64 nodes
