@@ -164,6 +164,7 @@ int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *fra
         }
     }
     if (kind == 0 && (rc = orbm_bf2nn_prepare(ctx))) return rc;
+    if (kind != 0 && (rc = orbm_ensure_image(ctx, 5, 0, nullptr))) return rc;   // the BoW searches' operand image: built before anything is staged
     // match rows + counts stay in a workspace of their own (ws2 belongs to the matchers and to the packer)
     const size_t o_counts = (rows * 4 + 255) / 256 * 256, need3 = o_counts + P * 4 + 256;
     if (need3 > ctx->ws3_bytes) {

@@ -673,6 +673,7 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
 // workgroup per pair whatever the batch size, 5 = the matrix-core form whatever the batch size
 int g_bow_variant = 0;
 int g_bow_split_below = 2048;   // batches of fewer pairs share each pair between several workgroups
+int g_bowm_wgs = 4096;          // matrix-core form: workgroups a small batch is spread over
 
 // Allocation-free variant (orbm_search_bow_batch_noalloc): the per-pair accumulators of the split path (30 histogram bins +
 // the match count, 32 ints per pair) live in this file-scope device array instead of the context's grow-only workspace.
@@ -703,12 +704,12 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         }
     }
     const size_t out_elems = (size_t)n_pairs * stride;
-    // Large batches of a7 / a8 take the matrix-core form (bowm.hip) when the ratio leaves few distances relevant; it reads
-    // the FeatureVector-ordered FP4 image of the frames, built here on first use (before anything is staged: the build
-    // uses the same staging buffers)
+    // a7 / a8 take the matrix-core form (bowm.hip) when the ratio leaves few distances relevant (not the allocation-free entry
+    // point: the form reads a FeatureVector-ordered copy of the frames' descriptors, built here on first use -- before
+    // anything is staged, the build uses the same staging buffers)
     const int capd = orbm_bow_cap(ratio);
-    const bool one_wg_per_pair = !static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3 || g_bow_variant == 5);
-    const bool use_mfma = mode != 2 && one_wg_per_pair && capd <= 128 && (g_bow_variant == 0 || g_bow_variant == 5);
+    const bool one_wg_per_pair = !static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3);
+    const bool use_mfma = mode != 2 && !static_acc && capd <= 128 && (g_bow_variant == 0 || g_bow_variant == 5);
     if (use_mfma) {
         int rc = io_on_device ? orbm_ensure_image(ctx, 5, 0, nullptr) : orbm_ensure_image(ctx, 5, n_pairs, frame_a);
         if (!rc && !io_on_device) rc = orbm_ensure_image(ctx, 5, n_pairs, frame_b);
@@ -731,12 +732,33 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
     // 64 / 256 / 512 / 1024 pairs 0.050 / 0.078 / 0.114 / 0.167 ms against 0.056 / 0.130 / 0.181 / 0.203 ms with one policy for all).
     const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
-    const int splits = one_wg_per_pair ? 1
+    // the matrix-core form keeps a workgroup about 50 us on a pair (a wave walks 25 nodes one after the other): below
+    // g_bowm_wgs workgroups in all a pair's nodes are dealt to several workgroups (at most 16)
+    const int splits = use_mfma ? (n_pairs >= g_bow_split_below ? 1 : std::max(1, std::min(16, g_bowm_wgs / n_pairs)))
+                       : one_wg_per_pair ? 1
                        : std::max(2, std::min(split_queries_on_lanes ? 16 : 32, (4096 + n_pairs - 1) / n_pairs));
     dim3 block(256);
     if (use_mfma) {
-        rc = orbm_launch_bowm(ctx, mode, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, capd, check_ori, stride, (int32_t *)dm, (int32_t *)dc);
+        int *acc = nullptr;
+        if (splits > 1) {
+            rc = orbm_ws2_reserve(ctx, (size_t)n_pairs * 32 * sizeof(int));
+            if (rc) return rc;
+            acc = (int *)ctx->ws2;
+            HIPCHK(ctx, hipMemsetAsync(acc, 0, (size_t)n_pairs * 32 * sizeof(int), ctx->stream));
+            if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
+        }
+        rc = orbm_launch_bowm(ctx, mode, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, capd, check_ori, stride, (int32_t *)dm,
+                              (int32_t *)dc, splits, acc);
         if (rc) return rc;
+        if (splits > 1) {
+            dim3 fgrid(n_pairs);
+            if (mode == 0)
+                hipLaunchKernelGGL((bow_finish_kernel<0>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+            else
+                hipLaunchKernelGGL((bow_finish_kernel<1>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+        }
     } else if (splits == 1) {
         dim3 grid(n_pairs);
 #define LAUNCH(M)                                                                                              \
@@ -785,6 +807,7 @@ int orbm_bow_scratch_resolve(orbm_ctx *ctx) {
 // tuning / test knob (not part of the public ABI): see g_bow_variant
 extern "C" void orbm__bow_variant(int v) { g_bow_variant = v; }
 extern "C" void orbm__bow_split_below(int n_pairs) { g_bow_split_below = n_pairs > 0 ? n_pairs : 2048; }
+extern "C" void orbm__bowm_wgs(int n) { g_bowm_wgs = n > 0 ? n : 4096; }
 
 extern "C" int orbm_search_bow_batch(orbm_ctx *ctx, int variant, int n_pairs, const int32_t *frame_a,
                                      const int32_t *frame_b, float ratio, int check_ori, int32_t stride,

@@ -84,22 +84,27 @@ __device__ __forceinline__ v8i expand_fp4(uint32_t w, uint32_t ones) {
 }
 
 // MODE 0: a7 (KF -> F), 1: a8 (KF -> KF)
-template <int MODE>
+// SPLIT = false: one workgroup per pair does everything.  SPLIT = true: `splits` workgroups share a pair's nodes (small
+// batches: a single SearchByBoW call would otherwise run on one CU); the match rows were pre-set to -1 by the caller, histogram
+// and count go to pair_acc (32 ints per pair) and bow_finish_kernel (bow.hip) applies the rotation filter afterwards.
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                    const int32_t *__restrict__ fb, float ratio, int capd, int check_ori, int stride,
-                                                   int32_t *__restrict__ match_all, int32_t *__restrict__ counts) {
+                                                   int32_t *__restrict__ match_all, int32_t *__restrict__ counts, int splits,
+                                                   int *__restrict__ pair_acc) {
     __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
-    const int p = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int p = SPLIT ? (int)blockIdx.x / splits : (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int part = SPLIT ? (int)blockIdx.x - p * splits : 0, nparts = SPLIT ? splits : 1;
     const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
-    for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    if (!SPLIT) for (int i = tid; i < nOut; i += 256) match[i] = -1;
     for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
     if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nmatches = 0;
@@ -160,9 +165,10 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         }
     };
 
-    for (int kb = 0; wave + 4 * kb < A.n_nodes; kb += 64) {
+    const int first_node = part * 4 + wave, node_step = 4 * nparts;
+    for (int kb = 0; first_node + node_step * kb < A.n_nodes; kb += 64) {
         // 64 of this wave's nodes, one per lane: the common-node lookup (lower_bound walk of :248-352) runs in parallel
-        const int ia = wave + 4 * (kb + lane);
+        const int ia = first_node + node_step * (kb + lane);
         uint32_t nA = 0, nB = 0, offA = 0, offB = 0;
         if (ia < A.n_nodes) {
             const uint32_t node_id = A.fv_node[ia];
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 const int src = in ? tg : 0;
                 const uint32_t nOffA = (uint32_t)__shfl((int)offA, src, 64), nOffB = (uint32_t)__shfl((int)offB, src, 64);
                 const uint32_t nNA = (uint32_t)__shfl((int)nA, src, 64), nNB = (uint32_t)__shfl((int)nB, src, 64);
-                const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu, rk = rec & 0xFFFFFu;     // rk = d << 13 | t: the scan's ranking
+                const uint32_t rq = rec >> 20, rt = rec & 0x1FFFu;
                 const int rd = (int)((rec >> 13) & 0x7Fu);
                 int idxA = 0, idxB = 0;
                 bool valid = false;
@@ -278,27 +284,32 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 // a node where every query has one relevant candidate that nobody else wants: best = that one, second best >= capd
                 if (valid && !contested_node && rd <= thr) accept_match(idxA, idxB);
                 if (!smask) continue;
-                // the other nodes: queries in the reference's order; a claim takes the candidate away from the later ones
-                bool active = valid && contested_node, gone = false;
-                const uint32_t okey = ((uint32_t)tg << 12) | rq;                            // (node, query position)
-                while (true) {
-                    const uint32_t cq = wave_min_u32(active ? okey : 0xFFFFFFFFu);
-                    if (cq == 0xFFFFFFFFu) break;
-                    const bool mine = active && okey == cq;
-                    const uint32_t k = (mine && !gone) ? rk : 0xFFFFFFFFu;
-                    const uint32_t b = wave_min_u32(k);
-                    const uint32_t s2 = wave_min_u32(k == b ? 0xFFFFFFFFu : k);           // (d, t) pairs of one query are distinct
+                // the other nodes: each takes its queries in the reference's order (ascending position), a claim takes the
+                // candidate away from the node's later queries; the nodes of the round advance side by side.  A record word
+                // (q << 20 | d << 13 | t) orders by query first, then by the scan's ranking (distance, position).
+                const int lo = in ? first : lane, hi = in ? last : lane;
+                auto node_min = [&](uint32_t x) -> uint32_t {       // minimum over the lanes of my node, in every one of them
+#pragma unroll
+                    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                        const uint32_t o = (uint32_t)__shfl_up((int)x, dlt, 64);
+                        if (lane - dlt >= lo) x = min(x, o);
+                    }
+                    return (uint32_t)__shfl((int)x, hi, 64);
+                };
+                bool open = valid && contested_node;               // record of a query not yet decided, candidate still free
+                while (__any(open)) {
+                    const uint32_t b = node_min(open ? rec : 0xFFFFFFFFu);                       // the node's next query and its best candidate
+                    const bool mine = open && (rec >> 20) == (b >> 20);
+                    const uint32_t s2 = node_min(mine && rec != b ? rec : 0xFFFFFFFFu);          // its second best ((d, t) pairs of one query are distinct)
                     if (b != 0xFFFFFFFFu) {
-                        const int bd = (int)(b >> 13);
-                        const bool second_passes = s2 == 0xFFFFFFFFu || (float)bd < __fmul_rn(ratio, (float)(int)(s2 >> 13));
-                        if (bd <= thr && second_passes) {                                  // :304-308 / :792-796
-                            const uint32_t tstar = b & 0x1FFFu;
-                            const int node_star = (int)(cq >> 12);
-                            if (k == b) accept_match(idxA, idxB);
-                            if (valid && tg == node_star && rt == tstar) gone = true;      // :312 / :799
+                        const int bd = (int)((b >> 13) & 0x7Fu);
+                        const bool second_passes = s2 == 0xFFFFFFFFu || (float)bd < __fmul_rn(ratio, (float)(int)((s2 >> 13) & 0x7Fu));
+                        if (bd <= thr && second_passes) {                                        // :304-308 / :792-796
+                            if (open && rec == b) accept_match(idxA, idxB);
+                            if (open && rt == (b & 0x1FFFu)) open = false;                       // :312 / :799: the candidate is taken
                         }
                     }
-                    active = active && !mine;
+                    if (mine) open = false;
                 }
             }
         };
@@ -360,6 +371,11 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     }
     if (my_matches) atomicAdd(&nmatches, my_matches);
     __syncthreads();
+    if (SPLIT) {
+        if (tid < ORBM_HISTO_LENGTH && hist[tid]) atomicAdd(&pair_acc[p * 32 + tid], hist[tid]);
+        if (tid == 0 && nmatches) atomicAdd(&pair_acc[p * 32 + 30], nmatches);
+        return;
+    }
     if (check_ori) {
         if (tid == 0) {
             int i1, i2, i3;
@@ -394,11 +410,13 @@ int orbm_bow_cap(float ratio) {
 }
 
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
-                     int check_ori, int stride, int32_t *dm, int32_t *dc) {
-    if (mode == 0)
-        hipLaunchKernelGGL((bowm_kernel<0>), dim3(n_pairs), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, dfb, ratio, capd, check_ori, stride, dm, dc);
-    else
-        hipLaunchKernelGGL((bowm_kernel<1>), dim3(n_pairs), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, dfb, ratio, capd, check_ori, stride, dm, dc);
+                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc) {
+#define LAUNCH(M, S)                                                                                                      \
+    hipLaunchKernelGGL((bowm_kernel<M, S>), dim3((unsigned)(n_pairs * (S ? splits : 1))), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, \
+                       dfb, ratio, capd, check_ori, stride, dm, dc, splits, pair_acc)
+    if (splits > 1) { if (mode == 0) LAUNCH(0, true); else LAUNCH(1, true); }
+    else { if (mode == 0) LAUNCH(0, false); else LAUNCH(1, false); }
+#undef LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }

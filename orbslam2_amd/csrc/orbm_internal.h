@@ -150,7 +150,7 @@ int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const c
 extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx);
 int orbm_bow_cap(float ratio);                        // bowm.hip: distances below it are the only ones that can change a SearchByBoW result
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
-                     int check_ori, int stride, int32_t *dm, int32_t *dc);   // bowm.hip: MFMA form, one workgroup per pair
+                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc);   // bowm.hip: MFMA form; splits > 1: that many workgroups per pair, accumulators in pair_acc
 int orbm_bow_scratch_resolve(orbm_ctx *ctx);         // bow.hip: device address of the static scratch array of ctx->device (orbm_create calls it)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more

@@ -96,12 +96,16 @@ struct Raw {
     }
 };
 
-static Raw MakeRaw(int n, const vector<Desc> &lmdesc, int lm0, int lmspan, int n_nodes, double stereo, double present, double bad, double noobs) {
+static Raw MakeRaw(int n, const vector<Desc> &lmdesc, int lm0, int lmspan, int n_nodes, double stereo, double present, double bad, double noobs,
+                   bool distinct = false) {
     Raw r; r.n = n;
+    vector<int> perm(lmspan);
+    for (int i = 0; i < lmspan; i++) perm[i] = i;
+    if (distinct) std::shuffle(perm.begin(), perm.end(), rng);     // distinct: no two keypoints of the frame observe the same landmark (n <= lmspan)
     r.sf.assign(8, 1.f); r.sigma2.assign(8, 1.f);
     for (int i = 1; i < 8; i++) { r.sf[i] = r.sf[i - 1] * 1.2f; r.sigma2[i] = r.sf[i] * r.sf[i]; }
     for (int i = 0; i < n; i++) {
-        int lm = lm0 + RI(lmspan);
+        int lm = lm0 + (distinct ? perm[i] : RI(lmspan));
         r.lm.push_back(lm);
         r.desc.push_back(Observe(lmdesc[lm], 0.06));
         r.x.push_back((float)U(16, 624)); r.y.push_back((float)U(16, 464));
@@ -199,8 +203,10 @@ static void TestBoW() {
             EXPECT(bad == 0, "KF-KF %d pointer mismatches", bad);
         }
     }
-    {   // per-call latency of the drop-in (snapshot + upload + kernel + download), warm
-        Raw ra = MakeRaw(2000, lm, 0, 1200, 100, 0.3, 0.85, 0.05, 0.1), rb = MakeRaw(2000, lm, 400, 1200, 100, 0.3, 0.8, 0.05, 0.1);
+    {   // per-call latency of the drop-in with both frames resident (flags check + lists + kernel + download), warm; every
+        // keypoint of a frame observes its own landmark here, as in a real keyframe
+        vector<Desc> lm2(3000); for (auto &d : lm2) d = RandDesc();
+        Raw ra = MakeRaw(2000, lm2, 0, 2400, 100, 0.3, 0.85, 0.05, 0.1, true), rb = MakeRaw(2000, lm2, 600, 2400, 100, 0.3, 0.8, 0.05, 0.1, true);
         KeyFrame A; Frame F; FillKF(A, ra); FillFrame(F, rb);
         ORBmatcher matcher(0.75f, true);
         vector<MapPoint *> got;
