@@ -82,8 +82,21 @@ try:
     win["algorithmic_bytes_batch_launch"] = 256 * (50000 * 53 + 2000 * 49 + 3073 * 4 + 2000 * 4)
     win["note"] = "batch = 256 instances x 50k queries, th=3, 64 distinct query sets; max_ns = the batch launch, min_ns = one instance alone"
     summ["windowed_search"] = win
-    bk = [r for r in rows if "bow_kernel" in r["Name"]][0]
-    summ["bow_kernel"] = {"name": bk["Name"][:70], "avg_ns": float(bk["AverageNs"]), "pairs_per_launch": 8192}
+    # SearchByBoW: the matrix-core form (bowm_kernel; the one-workgroup-per-pair launches are the 8192-pair measurement of
+    # `extra.search_bow_kfkf_*` and the 16384-pair launches of the config-5 triangle)
+    bks = [r for r in rows if "bowm_kernel" in r["Name"] or "bowq_kernel" in r["Name"] or "bow_kernel" in r["Name"]]
+    summ["bow_kernels"] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                            "max_ns": float(r["MaxNs"])} for r in bks]
+    try:
+        bsq, _ = counters("sq", "bowm_kernel<1, false>")
+        for extra_pass in ("sq2", "sq3"):
+            try:
+                more, _ = counters(extra_pass, "bowm_kernel<1, false>"); bsq.update(more)
+            except Exception:
+                pass
+        summ["bowm_kernel_counters_mean_per_launch"] = bsq
+    except Exception as e:
+        summ["bowm_counters_error"] = repr(e)
 except Exception as e:
     summ["secondary_error"] = repr(e)
 json.dump({"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_summary.json"}, open(f"profiles/{tag}_bf2nn_traffic.json", "w"))
