@@ -219,7 +219,8 @@ int orbm_stereo_match_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_lef
  * descriptor with the least median Hamming distance to all of them (median = element (int)(0.5*(N-1)) of the sorted
  * row, first row wins ties), or -1 for an empty list (the reference returns without touching mDescriptor).  The
  * caller then sets mDescriptor = that row.  Replaces the per-point calls at LocalMapping.cc:289,780,926,
- * LoopClosing.cc:918, Tracking.cc:673,864,1461.  Limit: 512 observations per point (ORBM_ELIMIT beyond). */
+ * LoopClosing.cc:918, Tracking.cc:673,864,1461.  Any number of observations per point (up to 512 a point is handled in
+ * registers + LDS, beyond that by a slower streaming form of the same kernel; same results). */
 int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_t *off, const uint8_t *desc,
                                        int32_t *best_idx, int io_on_device);
 

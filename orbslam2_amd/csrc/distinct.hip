@@ -5,13 +5,15 @@
 // One wavefront per point.  The descriptors sit in LDS; for row i the wave reads descriptor i (broadcast) and lane l
 // computes d(i, l), d(i, l + 64), ... (at most DIST_MAX_N / 64 values per lane, in registers).  The median needs no
 // sort: distances are integers in [0, 256], so the k-th smallest is found by a 9-step bisection on the value with a
-// ballot + popcount per step.
+// ballot + popcount per step.  A point with more than DIST_MAX_N observations (the reference has no limit) does not fit
+// this form: its wave streams the rows from global memory instead and finds each row's median in a 257-bin histogram
+// in LDS -- slow (N^2 / 64 row loads) and rare.
 #include <limits.h>
 #include "orbm_internal.h"
 
 namespace {
 
-constexpr int DIST_MAX_N = 512;          // observations per map point (the reference has no limit; see orbmatch.h)
+constexpr int DIST_MAX_N = 512;          // observations per map point that the register form holds; above: the histogram form
 constexpr int DIST_PER_LANE = DIST_MAX_N / 64;
 constexpr int DIST_WAVES = 4;
 
@@ -26,6 +28,46 @@ __global__ __launch_bounds__(64 * DIST_WAVES) void distinctive_kernel(int n_poin
     if (N <= 0) { if (lane == 0) best_idx[p] = -1; return; }                              // :384-385 / :405-406
     uint4 *l_desc = reinterpret_cast<uint4 *>(lds) + (size_t)wave * (2 * DIST_MAX_N);
     const uint4 *g = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)b;
+    if (N > DIST_MAX_N) {                                                                  // wave-uniform
+        int *hist = reinterpret_cast<int *>(l_desc);                                      // 320 bins (257 used)
+        const int k = (int)(0.5 * (double)(N - 1));                                       // :434
+        int bestMedian = INT_MAX, bestI = 0;
+        for (int i = 0; i < N; i++) {
+            for (int t = lane; t < 320; t += 64) hist[t] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 lo = g[2 * i], hi = g[2 * i + 1];
+            const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            for (int j = lane; j < N; j += 64) {
+                const uint4 clo = g[2 * j], chi = g[2 * j + 1];
+                const uint32_t c[8] = {clo.x, clo.y, clo.z, clo.w, chi.x, chi.y, chi.z, chi.w};
+                atomicAdd(&hist[hamming256(q, c)], 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // lane l owns bins 5 l .. 5 l + 4; the median is the first value whose running count exceeds k
+            int c5[5], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 5; u++) { c5[u] = hist[5 * lane + u]; sum += c5[u]; }
+            int incl = sum;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int up = __shfl_up(incl, dlt, 64);
+                if (lane >= dlt) incl += up;
+            }
+            int med = INT_MAX, run = incl - sum;
+            if (run <= k && k < incl) {
+#pragma unroll
+                for (int u = 0; u < 5; u++) { run += c5[u]; if (run > k && med == INT_MAX) med = 5 * lane + u; }
+            }
+#pragma unroll
+            for (int offs = 32; offs > 0; offs >>= 1) med = min(med, __shfl_xor(med, offs, 64));
+            if (med < bestMedian) { bestMedian = med; bestI = i; }                        // :436-440 (strict <: first wins)
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) best_idx[p] = bestI;
+        return;
+    }
     for (int i = lane; i < 2 * N; i += 64) l_desc[i] = g[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -78,8 +120,6 @@ extern "C" int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, c
         for (int p = 0; p < n_points; p++) {
             const int n = off[p + 1] - off[p];
             if (n < 0) return orbm_fail(ctx, ORBM_EINVAL, "distinctive_descriptors_batch: off not monotone at %d", p);
-            if (n > DIST_MAX_N)
-                return orbm_fail(ctx, ORBM_ELIMIT, "distinctive_descriptors_batch: point %d has %d observations (limit %d)", p, n, DIST_MAX_N);
         }
         total = (size_t)off[n_points];
         if (total > 0 && !desc) return orbm_fail(ctx, ORBM_EINVAL, "distinctive_descriptors_batch: null descriptors");

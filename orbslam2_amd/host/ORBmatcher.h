@@ -105,7 +105,7 @@ protected:
 
 // Extension (not in the reference): MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:363-449) for many map points
 // in one launch; sets mDescriptor of every point exactly as the per-point method would.  Use it where the reference
-// loops over points (LocalMapping.cc:289,780,926, LoopClosing.cc:918).  Points with more than 512 observations throw.
+// loops over points (LocalMapping.cc:289,780,926, LoopClosing.cc:918).
 void ComputeDistinctiveDescriptorsBatch(const std::vector<MapPoint *> &vpMapPoints);
 
 }  // namespace ORB_SLAM2

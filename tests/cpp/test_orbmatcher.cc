@@ -979,9 +979,17 @@ static void TestKeyFrameDatabase() {
     }
     KeyFrameDatabase db(voc);
     vector<int> order;                                             // add order; a few are erased again, two re-added
-    for (int i = 0; i < NKF; i++) { db.add(kfs[i].get()); order.push_back(i); }
-    for (int e : {5, 77, 78, 130}) { db.erase(kfs[e].get()); order.erase(std::find(order.begin(), order.end(), e)); }
-    for (int e : {77, 5}) { db.add(kfs[e].get()); order.push_back(e); }
+    // add / erase come from another thread than the Detect* calls below, as in the reference (LocalMapping adds,
+    // LoopClosing and Tracking query): the database's device copies must not belong to the adding thread's context
+    {
+        std::thread local_mapping([&] {
+            for (int i = 0; i < NKF; i++) { db.add(kfs[i].get()); order.push_back(i); }
+            for (int e : {5, 77, 78, 130}) { db.erase(kfs[e].get()); order.erase(std::find(order.begin(), order.end(), e)); }
+        });
+        local_mapping.join();
+        std::thread again([&] { for (int e : {77, 5}) { db.add(kfs[e].get()); order.push_back(e); } });
+        again.join();
+    }
 
     // the oracle's flat database
     std::map<KeyFrame *, int> index;
@@ -1050,7 +1058,15 @@ static void TestKeyFrameDatabase() {
     EXPECT(bad_lists == 0, "KeyFrameDatabase: %d candidate lists differ", bad_lists);
     EXPECT(bad_fields == 0, "KeyFrameDatabase: %d bookkeeping fields differ", bad_fields);
     EXPECT(total_loop > 20 && total_reloc > 30, "KeyFrameDatabase: too few candidates (%d loop, %d reloc)", total_loop, total_reloc);
-    db.clear();
+    {   // a third thread queries, then clears
+        int n_other = -1;
+        Frame G; G.mnId = 998; bow_of(1, G.mBowVec);
+        const size_t n_here = db.DetectRelocalizationCandidates(&G).size();
+        G.mnId = 997;                                              // a new query id: the per-keyframe fields restart
+        std::thread tracking([&] { n_other = (int)db.DetectRelocalizationCandidates(&G).size(); db.clear(); });
+        tracking.join();
+        EXPECT(n_other == (int)n_here && n_here > 0, "query from another thread: %d candidates vs %zu", n_other, n_here);
+    }
     Frame F; F.mnId = 999; bow_of(0, F.mBowVec);
     EXPECT(db.DetectRelocalizationCandidates(&F).empty(), "cleared database must return nothing");
     printf("KeyFrameDatabase done: %d loop + %d reloc candidates over 60 queries; DetectLoopCandidates %.3f ms, DetectRelocalizationCandidates %.3f ms per call (%d keyframes)\n",

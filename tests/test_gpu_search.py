@@ -387,10 +387,10 @@ def test_window_free_parity(ctx, orc, chi2, dist_th, stereo):
 
 def test_distinctive_descriptors_parity(ctx, orc):
     """MapPoint::ComputeDistinctiveDescriptors batched over map points: empty lists, single observations, ties
-    (identical descriptors), lists above one wavefront, the 512-observation limit."""
-    from orbslam2_amd.matcher import OrbmError
+    (identical descriptors), lists above one wavefront, and on both sides of 512 observations, where the kernel changes
+    from its register form to the streaming form (the reference has no limit)."""
     rng = np.random.default_rng(77)
-    sizes = [0, 1, 2, 3, 5, 8, 64, 65, 130, 512] + list(rng.integers(1, 40, 400))
+    sizes = [0, 1, 2, 3, 5, 8, 64, 65, 130, 512, 513, 700, 1100] + list(rng.integers(1, 40, 400))
     descs, off = [], [0]
     for n in sizes:
         lm = synth.random_descriptors(rng, 1)[0]
@@ -401,9 +401,9 @@ def test_distinctive_descriptors_parity(ctx, orc):
     got = ctx.distinctive_descriptors(np.array(off), np.concatenate(descs))
     want = np.array([orc.distinctive_descriptor(d) for d in descs])
     assert np.array_equal(got, want)
-    assert (want[10:] >= 0).all() and len(set(want[10:])) > 5
-    with pytest.raises(OrbmError):
-        ctx.distinctive_descriptors(np.array([0, 513]), np.zeros((513, 32), np.uint8))
+    assert (want[13:] >= 0).all() and len(set(want[13:])) > 5
+    # all-equal descriptors above the limit: every median is 0, the first row wins
+    assert ctx.distinctive_descriptors(np.array([0, 513]), np.zeros((513, 32), np.uint8))[0] == 0
 
 
 def test_stereo_match_parity(ctx, orc):
