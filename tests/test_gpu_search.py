@@ -814,6 +814,62 @@ def test_bow_score_parity(ctx, orc):
     ctx.free_bowvecs(ids)
 
 
+def test_bow_search_follows_a_rebuilt_feature_vector(ctx, orc):
+    """The matrix-core form of SearchByBoW reads a copy of each frame's descriptors in FeatureVector order, built the first
+    time the frame is searched.  When ComputeBoW on the device replaces a frame's FeatureVector that copy is stale: the
+    next search must follow the new grouping, and a frame freed and its handle reused must not inherit the old copy."""
+    vocab_a = synth.make_vocabulary(seed=81, k=8, depth=3, flip=0.15)
+    vocab_b = synth.make_vocabulary(seed=82, k=6, depth=4, flip=0.2)
+    rng = np.random.default_rng(83)
+    lm = synth.vocabulary_features(rng, vocab_a, 2500, flip=0.05)
+    frames = []
+    for k in range(4):
+        sel = (300 * k + rng.integers(0, 1500, 900)) % 2500
+        flags = np.where(rng.random(900) < 0.9, MP_PRESENT, 0).astype(np.uint8)
+        frames.append(synth.make_frame(rng, lm, sel, with_fv=False, mp_flags=flags))
+    ids = ctx.upload_frames(frames)
+    pa, pb = np.meshgrid(np.arange(4), np.arange(4))
+    pa, pb = pa.ravel(), pb.ravel()
+
+    def regroup(f, vocab, levelsup):
+        _, _, (f.fv_node, f.fv_off, f.fv_idx), _ = orc.transform(vocab, f.desc, levelsup, want_bow=True)
+
+    def check(what):
+        tot = 0
+        for variant in (0, 1):
+            counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=900)
+            for t, (i, j) in enumerate(zip(pa, pb)):
+                c, m, _ = orc.search_bow(variant, frames[i], frames[j], 0.75, True)
+                assert counts[t] == c and np.array_equal(match[t, :len(m)], m), (what, variant, i, j)
+                tot += c
+        assert tot > 50, (what, tot)
+
+    va = ctx.upload_vocabulary(vocab_a); vb = ctx.upload_vocabulary(vocab_b)
+    live = list(ids)
+    try:
+        ctx.compute_bow(va, ids, 2, want_ids=False)
+        for f in frames: regroup(f, vocab_a, 2)
+        check("first grouping")                               # builds the FeatureVector-ordered copies
+        ctx.compute_bow(vb, ids, 3, want_ids=False)           # other tree, other level: other nodes
+        for f in frames: regroup(f, vocab_b, 3)
+        check("after ComputeBoW with another vocabulary")
+        ctx.compute_bow(va, ids[:2], 1, want_ids=False)       # only two of the frames regrouped
+        for f in frames[:2]: regroup(f, vocab_a, 1)
+        check("two of four frames regrouped")
+        # handles are recycled: a new frame in an old slot gets its own copy
+        ctx.free_frames(ids[2:]); live = list(ids[:2])
+        other = [synth.make_frame(rng, lm, rng.integers(0, 2500, 700), mp_flags=np.full(700, MP_PRESENT, np.uint8)) for _ in range(2)]
+        ids2 = ctx.upload_frames(other); live += list(ids2)
+        assert set(ids2.tolist()) & set(ids[2:].tolist())
+        counts, match = ctx.search_bow(1, np.array([ids2[0], ids2[1]]), np.array([ids2[1], ids2[0]]), 0.75, True, stride=700)
+        for t, (i, j) in enumerate(((0, 1), (1, 0))):
+            c, m, _ = orc.search_bow(1, other[i], other[j], 0.75, True)
+            assert counts[t] == c and np.array_equal(match[t, :len(m)], m), ("recycled handle", i, j)
+    finally:
+        ctx.free_vocabulary(va); ctx.free_vocabulary(vb)
+        ctx.free_frames(np.array(live, np.int32))
+
+
 @pytest.mark.gpu
 def test_relocalisation_chain_stays_on_the_device(ctx, orc):
     """Config 4 end to end without a host-built BoW structure: keyframes and a query frame uploaded with descriptors
