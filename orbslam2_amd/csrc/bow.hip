@@ -53,19 +53,6 @@ __device__ __forceinline__ int find_node(gptr<const uint32_t> nodes, int n, uint
     return (lo < n && nodes[lo] == key) ? lo : -1;
 }
 
-// ORBmatcher.cc:179-206
-__device__ __forceinline__ bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, float sigma2,
-                                                         const float *F12) {
-    const float a = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[0]), __fmul_rn(y1, F12[3])), F12[6]);
-    const float b = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[1]), __fmul_rn(y1, F12[4])), F12[7]);
-    const float c = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[2]), __fmul_rn(y1, F12[5])), F12[8]);
-    const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
-    const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
-    if (den == 0) return false;
-    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-    return (double)dsqr < __dmul_rn(3.84, (double)sigma2);
-}
-
 // MODE 0: a7 (KF -> F), 1: a8 (KF -> KF), 2: a9 (triangulation)
 // SPLIT = false: one workgroup per pair does everything (large batches: the chip is full anyway).
 // SPLIT = true : `splits` workgroups share a pair's nodes (a single SearchByBoW call would otherwise run on one CU);
@@ -707,9 +694,9 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     // a7 / a8 take the matrix-core form (bowm.hip) when the ratio leaves few distances relevant (not the allocation-free entry
     // point: the form reads a FeatureVector-ordered copy of the frames' descriptors, built here on first use -- before
     // anything is staged, the build uses the same staging buffers)
-    const int capd = orbm_bow_cap(ratio);
+    const int capd = mode == 2 ? ORBM_TH_LOW + 1 : orbm_bow_cap(ratio);   // a9 has no ratio test: relevant = d <= TH_LOW
     const bool one_wg_per_pair = !static_acc && (n_pairs >= g_bow_split_below || g_bow_variant == 3);
-    const bool use_mfma = mode != 2 && !static_acc && capd <= 128 && (g_bow_variant == 0 || g_bow_variant == 5);
+    const bool use_mfma = !static_acc && capd <= 128 && (g_bow_variant == 0 || g_bow_variant == 5);
     if (use_mfma) {
         int rc = io_on_device ? orbm_ensure_image(ctx, 5, 0, nullptr) : orbm_ensure_image(ctx, 5, n_pairs, frame_a);
         if (!rc && !io_on_device) rc = orbm_ensure_image(ctx, 5, n_pairs, frame_b);
@@ -748,12 +735,15 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
             if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
         }
         rc = orbm_launch_bowm(ctx, mode, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, capd, check_ori, stride, (int32_t *)dm,
-                              (int32_t *)dc, splits, acc);
+                              (int32_t *)dc, splits, acc, only_stereo, (const float *)df12, (const float *)dep);
         if (rc) return rc;
         if (splits > 1) {
             dim3 fgrid(n_pairs);
             if (mode == 0)
                 hipLaunchKernelGGL((bow_finish_kernel<0>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+            else if (mode == 2)
+                hipLaunchKernelGGL((bow_finish_kernel<2>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
                                    check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
             else
                 hipLaunchKernelGGL((bow_finish_kernel<1>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,

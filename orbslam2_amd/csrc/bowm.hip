@@ -83,7 +83,9 @@ __device__ __forceinline__ v8i expand_fp4(uint32_t w, uint32_t ones) {
     return (v8i){(int)and_or(w << 3, sign, ones), (int)and_or(w << 2, sign, ones), (int)and_or(w << 1, sign, ones), (int)and_or(w, sign, ones), 0, 0, 0, 0};
 }
 
-// MODE 0: a7 (KF -> F), 1: a8 (KF -> KF)
+// MODE 0: a7 (KF -> F), 1: a8 (KF -> KF), 2: a9 (SearchForTriangulation, ORBmatcher.cc:868-1093: no ratio test and no claims --
+// a query takes the candidate of least distance <= TH_LOW among those that pass the stereo / epipole / epipolar-line
+// gates, the LAST one among equals; relevant = d <= TH_LOW, the gates are evaluated per record)
 // SPLIT = false: one workgroup per pair does everything.  SPLIT = true: `splits` workgroups share a pair's nodes (small
 // batches: a single SearchByBoW call would otherwise run on one CU); the match rows were pre-set to -1 by the caller, histogram
 // and count go to pair_acc (32 ints per pair) and bow_finish_kernel (bow.hip) applies the rotation filter afterwards.
@@ -91,7 +93,8 @@ template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                    const int32_t *__restrict__ fb, float ratio, int capd, int check_ori, int stride,
                                                    int32_t *__restrict__ match_all, int32_t *__restrict__ counts, int splits,
-                                                   int *__restrict__ pair_acc) {
+                                                   int *__restrict__ pair_acc, int only_stereo, const float *__restrict__ f12all,
+                                                   const float *__restrict__ epiall) {
     __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
@@ -121,7 +124,29 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     uint8_t *tags = s_tags[wave];
     int my_matches = 0;
 
-    auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815
+    float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float ex = 0.f, ey = 0.f;
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) F12[i] = f12all[(size_t)p * 9 + i];
+        ex = epiall[2 * p]; ey = epiall[2 * p + 1];
+    }
+    // a9: the gates of one (query, candidate) pair that do not depend on the distance (:932-941, :970-981, :1001-1017)
+    auto triang_gates = [&](int idxA, int idxB) -> bool {
+        const uint32_t fA = A.mp_flags[idxA], fB = B.mp_flags[idxB];
+        const bool st1 = A.uright[idxA] >= 0, st2 = B.uright[idxB] >= 0;
+        if ((fA & ORBM_MP_PRESENT) || (only_stereo && !st1)) return false;                // :932, :939-941
+        if ((fB & ORBM_MP_PRESENT) || (only_stereo && !st2)) return false;                // :970, :979-981
+        const float x2 = B.x[idxB], y2 = B.y[idxB];
+        const int oct2 = B.octave[idxB];
+        if (!st1 && !st2) {
+            const float dex = __fsub_rn(ex, x2), dey = __fsub_rn(ey, y2);
+            if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, B.sf[oct2])) return false;  // :1007
+        }
+        return check_dist_epipolar_line(A.x[idxA], A.y[idxA], x2, y2, B.sigma2[oct2], F12);                        // :1014
+    };
+
+    auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815 / :1021-1041
         if (MODE == 0) match[idxB] = idxA; else match[idxA] = idxB;
         if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[idxB])], 1);
         my_matches++;
@@ -129,6 +154,28 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
 
     // the reference's loops as they stand, for one node: queries in order, the 64 lanes over the candidates
     auto generic_node = [&](uint32_t offA, uint32_t nA, uint32_t offB, uint32_t nB) {
+        if (MODE == 2) {
+            for (uint32_t qa = 0; qa < nA; qa++) {
+                const int idxA = (int)A.fv_idx[offA + qa];
+                if (A.mp_flags[idxA] & ORBM_MP_PRESENT) continue;                         // :932
+                uint32_t q[8];
+                load_row(A.desc, idxA, q);
+                uint32_t best = INITKEY;
+                for (uint32_t cb = 0; cb < nB; cb += 64) {
+                    const uint32_t c = cb + (uint32_t)lane;
+                    if (c >= nB) continue;
+                    const int idxB = (int)B.fv_idx[offB + c];
+                    uint32_t cd[8];
+                    load_row(B.desc, idxB, cd);
+                    const uint32_t d = hamming256(q, cd);
+                    if (d > ORBM_TH_LOW || !triang_gates(idxA, idxB)) continue;           // :993 (first half) and the gates
+                    best = min(best, (d << 16) | (0xFFFFu - c));                          // "dist > bestDist -> skip": an equal distance replaces
+                }
+                best = wave_min_u32(best);
+                if (best != INITKEY && lane == 0) accept_match(idxA, (int)B.fv_idx[offB + (0xFFFFu - (best & 0xFFFFu))]);   // :1021
+            }
+            return;
+        }
         for (uint32_t qa = 0; qa < nA; qa++) {
             const int idxA = (int)A.fv_idx[offA + qa];
             const uint32_t fA = A.mp_flags[idxA];
@@ -248,11 +295,15 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 if (in && rq < nNA && rt < nNB) {
                     idxA = (int)A.fv_idx[nOffA + rq];
                     idxB = (int)B.fv_idx[nOffB + rt];
-                    const uint32_t fA = A.mp_flags[idxA];
-                    valid = (fA & ORBM_MP_PRESENT) && !(fA & ORBM_MP_BAD);                  // :263-267 / :746-749
-                    if (MODE == 1) {
-                        const uint32_t fB = B.mp_flags[idxB];
-                        valid = valid && (fB & ORBM_MP_PRESENT) && !(fB & ORBM_MP_BAD);      // :766-770
+                    if (MODE == 2) {
+                        valid = triang_gates(idxA, idxB);
+                    } else {
+                        const uint32_t fA = A.mp_flags[idxA];
+                        valid = (fA & ORBM_MP_PRESENT) && !(fA & ORBM_MP_BAD);              // :263-267 / :746-749
+                        if (MODE == 1) {
+                            const uint32_t fB = B.mp_flags[idxB];
+                            valid = valid && (fB & ORBM_MP_PRESENT) && !(fB & ORBM_MP_BAD);  // :766-770
+                        }
                     }
                 }
                 start += take;
@@ -265,6 +316,24 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 const unsigned long long later = lane < 63 ? (heads | (take < 64 ? 1ull << take : 0ull)) >> (lane + 1) : 0ull;
                 const int last = later ? lane + __builtin_ctzll(later) : take - 1;
                 const int run = last - first + 1;
+                if (MODE == 2) {
+                    // a9: queries are independent; per (node, query) the record of least distance, the last position among equals
+                    const int lo2 = in ? first : lane, hi2 = in ? last : lane;
+                    const uint32_t key2 = (rq << 20) | ((uint32_t)rd << 13) | (0x1FFFu - rt);
+                    bool open2 = valid;
+                    while (__any(open2)) {
+                        uint32_t x = open2 ? key2 : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                            const uint32_t o = (uint32_t)__shfl_up((int)x, dlt, 64);
+                            if (lane - dlt >= lo2) x = min(x, o);
+                        }
+                        const uint32_t b = (uint32_t)__shfl((int)x, hi2, 64);
+                        if (open2 && key2 == b) accept_match(idxA, idxB);
+                        if (open2 && rq == (b >> 20)) open2 = false;
+                    }
+                    continue;
+                }
                 // does another valid record of my node name my query or my candidate?  (cyclic walk over the node's lanes)
                 int max_run = in ? run : 0;
 #pragma unroll
@@ -410,12 +479,13 @@ int orbm_bow_cap(float ratio) {
 }
 
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
-                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc) {
+                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc, int only_stereo,
+                     const float *df12, const float *dep) {
 #define LAUNCH(M, S)                                                                                                      \
     hipLaunchKernelGGL((bowm_kernel<M, S>), dim3((unsigned)(n_pairs * (S ? splits : 1))), dim3(256), 0, ctx->stream, ctx->d_frames, dfa, \
-                       dfb, ratio, capd, check_ori, stride, dm, dc, splits, pair_acc)
-    if (splits > 1) { if (mode == 0) LAUNCH(0, true); else LAUNCH(1, true); }
-    else { if (mode == 0) LAUNCH(0, false); else LAUNCH(1, false); }
+                       dfb, ratio, capd, check_ori, stride, dm, dc, splits, pair_acc, only_stereo, df12, dep)
+    if (splits > 1) { if (mode == 0) LAUNCH(0, true); else if (mode == 1) LAUNCH(1, true); else LAUNCH(2, true); }
+    else { if (mode == 0) LAUNCH(0, false); else if (mode == 1) LAUNCH(1, false); else LAUNCH(2, false); }
 #undef LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;

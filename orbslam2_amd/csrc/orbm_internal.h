@@ -150,7 +150,8 @@ int orbm_check_qsets(orbm_ctx *ctx, int n, const int32_t *ids, int kind, const c
 extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx);
 int orbm_bow_cap(float ratio);                        // bowm.hip: distances below it are the only ones that can change a SearchByBoW result
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
-                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc);   // bowm.hip: MFMA form; splits > 1: that many workgroups per pair, accumulators in pair_acc
+                     int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc, int only_stereo,
+                     const float *df12, const float *dep);   // bowm.hip: MFMA form; splits > 1: that many workgroups per pair, accumulators in pair_acc
 int orbm_bow_scratch_resolve(orbm_ctx *ctx);         // bow.hip: device address of the static scratch array of ctx->device (orbm_create calls it)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize stays with the function once set: ask the runtime only when a launch needs more
@@ -271,6 +272,19 @@ __device__ __forceinline__ int rot_bin(float a1, float a2) {
     int bin = (int)roundf(__fmul_rn(rot, factor));
     if (bin == ORBM_HISTO_LENGTH) bin = 0;
     return bin;
+}
+
+// ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cc:179-206 (float products and sums in source order, the compare in double)
+__device__ __forceinline__ bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, float sigma2,
+                                                         const float *F12) {
+    const float a = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[0]), __fmul_rn(y1, F12[3])), F12[6]);
+    const float b = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[1]), __fmul_rn(y1, F12[4])), F12[7]);
+    const float c = __fadd_rn(__fadd_rn(__fmul_rn(x1, F12[2]), __fmul_rn(y1, F12[5])), F12[8]);
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
+    const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    if (den == 0) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    return (double)dsqr < __dmul_rn(3.84, (double)sigma2);
 }
 
 // ComputeThreeMaxima, ORBmatcher.cc:2135-2178 (single lane)

@@ -242,7 +242,7 @@ __device__ __forceinline__ int word_tail(uint32_t head2, uint32_t head3) {
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups) {
+                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[COLLECT_THREADS / 64];
@@ -318,10 +318,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const bool stereo_gate = has_stereo_gate<MODE>(S);
     const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
     const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
-    constexpr int WAVES = COLLECT_THREADS / 64;
     // queries sorted together: `groups` rows of 64 per wave (2; 1 when the launch has few instances, so that one instance
     // spreads over more workgroups)
-    const int SUPER = groups * COLLECT_THREADS;
+    // qt = queries per row of a super-chunk (a multiple of 64, COLLECT_THREADS unless the launch has too few queries to give
+    // every CU a full workgroup's worth: then only the first qt / 64 waves take queries and the instance spreads wider)
+    const int SUPER = groups * qt, QW = qt >> 6;
     // A wave costs what its longest walk costs and window areas differ by more than 10x between pyramid levels, so
     // the queries of a super-chunk are counting-sorted by window area (in cells) and each wave takes one heavy and one
     // light group of 64 (results are written at the query's own position).
@@ -333,9 +334,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         int cls[2], rank[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if (h >= groups) { cls[h] = 0; rank[h] = 0; continue; }
+            if (h >= groups || tid >= qt) { cls[h] = 0; rank[h] = 0; continue; }
             // cost class = the window's area in cells, from its half-size alone (no window arithmetic here)
-            const float rr = load_radius<MODE>(P, F, S, sc * SUPER + h * COLLECT_THREADS + tid);
+            const float rr = load_radius<MODE>(P, F, S, sc * SUPER + h * qt + tid);
             int c = 0;
             if (rr >= 0.f) {
                 const int area = (int)((2.f * rr * inv_w + 2.f) * (2.f * rr * inv_h + 2.f));
@@ -358,12 +359,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if (h >= groups) continue;
-            l_perm[l_bucket[cls[h]] + rank[h]] = (uint16_t)(h * COLLECT_THREADS + tid);
+            if (h >= groups || tid >= qt) continue;
+            l_perm[l_bucket[cls[h]] + rank[h]] = (uint16_t)(h * qt + tid);
         }
         __syncthreads();
-      for (int h = 0; h < groups; h++) {
-        const int group = h == 0 ? wave : 2 * WAVES - 1 - wave;
+      for (int h = 0; h < groups && wave < QW; h++) {
+        const int group = h == 0 ? wave : 2 * QW - 1 - wave;
         const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
         Query q = load_params<MODE>(P, F, S, qi);
         if (q.valid) load_desc<MODE>(S, qi, q);
@@ -1042,10 +1043,17 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
         const int groups = (long long)n_inst * wgs_per_inst < wg_target ? 1 : 2;
         if (groups == 1) wgs_per_inst = std::max(1, std::min((wg_target + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
+        // still fewer workgroups than CUs (one large instance): narrower rows, so that the instance spreads over the chip
+        int qt = COLLECT_THREADS;
+        if (groups == 1 && (long long)n_inst * wgs_per_inst < wg_target) {
+            const long long per_wg = ((long long)waves_per_inst * 64 * n_inst + wg_target - 1) / wg_target;
+            qt = (int)std::min<long long>(COLLECT_THREADS, std::max<long long>(64, (per_wg + 63) / 64 * 64));
+            wgs_per_inst = std::max(1, (waves_per_inst * 64 + qt - 1) / qt);
+        }
         const size_t lds = collect_lds_bytes(cfg);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups);
+                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
         return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail, tcap);

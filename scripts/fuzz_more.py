@@ -22,6 +22,7 @@ for s in range(first, first + n_seeds):
         T.test_claim_rounds_fuzz_near_thresholds(ctx, orc)
     for form in FORMS:
         T.test_bow_fuzz_near_thresholds(ctx, orc, form)
+        T.test_triang_fuzz_crowded_nodes(ctx, orc, form)
     print("seed offset %d ok (%.0f s)" % (1000 * s, time.time() - t0), flush=True)
 ctx.close()
 print("ALL %d SEEDS OK" % n_seeds)

@@ -231,6 +231,48 @@ def test_triang_last_wins_on_equal_distance(ctx, orc):
     ctx.free_frames(ids)
 
 
+@pytest.mark.parametrize("form", [1, 2, 5])
+def test_triang_fuzz_crowded_nodes(ctx, orc, form):
+    """SearchForTriangulation in all kernel forms on crowded nodes: small landmark pools (many candidates at or below
+    TH_LOW for one query, equal distances: the last one wins), random stereo flags and map points, both only_stereo
+    settings, small and large batches."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(777 + form + _fuzz_offset())
+    kfs = []
+    for trial in range(12):
+        n = int(rng.integers(60, 500))
+        lm_desc = synth.random_descriptors(rng, int(rng.integers(6, 60)))
+        lm = rng.integers(0, len(lm_desc), n)
+        flags = np.where(rng.random(n) < 0.4, MP_PRESENT | MP_OBS, 0).astype(np.uint8)
+        ur = np.where(rng.random(n) < 0.4, rng.uniform(1, 600, n), -1.0).astype(np.float32)
+        # a landmark sits on the same image row (+- a pixel) in every keyframe: with the horizontal epipolar lines below its
+        # observations pass CheckDistEpipolarLine, at the coarse octaves also those of its neighbours
+        y = (20.0 + (lm * 37 % 440) + rng.normal(0, 0.8, n)).astype(np.float32)
+        kfs.append(synth.make_frame(rng, lm_desc, lm, y=y, mp_flags=flags, uright=ur, p_flip=float(rng.choice([0.03, 0.08, 0.1])),
+                                    n_nodes=int(rng.choice([1, 4, 12])), octave=rng.integers(0, 8, n).astype(np.int32)))
+    ids = ctx.upload_frames(kfs)
+    P = 560
+    pa = rng.integers(0, len(kfs), P); pb = rng.integers(0, len(kfs), P)
+    f12 = np.tile(np.array([0, 0, 0, 0, 0, 1, 0, -1, 0], np.float32), (P, 1)) + rng.normal(0, 3e-6, (P, 9)).astype(np.float32)
+    ep = np.stack([rng.uniform(0, 640, P), rng.uniform(0, 480, P)], axis=1).astype(np.float32)
+    try:
+        L.orbm__bow_variant(form)
+        L.orbm__bow_split_below(512)                          # 560 pairs: one workgroup per pair, 30 pairs: split path
+        for only_stereo in (False, True):
+            want = [orc.search_triang(kfs[pa[k]], kfs[pb[k]], f12[k], ep[k], only_stereo, True) for k in range(P)]
+            assert sum(w[0] for w in want) > 100
+            for lo, hi in ((0, P), (0, 30)):
+                counts, match = ctx.search_triang(ids[pa[lo:hi]], ids[pb[lo:hi]], f12[lo:hi].reshape(-1, 3, 3), ep[lo:hi], only_stereo, True, stride=500)
+                for k in range(lo, hi):
+                    wc, wm, _ = want[k]
+                    assert counts[k - lo] == wc and np.array_equal(match[k - lo, :len(wm)], wm), (form, only_stereo, hi, k)
+    finally:
+        L.orbm__bow_variant(0)
+        L.orbm__bow_split_below(2048)
+    ctx.free_frames(ids)
+
+
 @pytest.mark.parametrize("th", [1.0, 3.0, 5.0])
 @pytest.mark.parametrize("stereo", [False, True])
 def test_proj_points_parity(ctx, orc, th, stereo):
