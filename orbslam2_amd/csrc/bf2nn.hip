@@ -488,6 +488,131 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
     if (l == 0 && accepted) atomicAdd(&counts[p], accepted);
 }
 
+
+// ---- the FP4 form again, WITHOUT LDS (variant 12) ----------------------------------------------------------------------
+// Candidate rows come straight from the frame's raw descriptors (32 B per row: lane (col, h) reads the 16-byte half h of row
+// col, one coalesced 1 KB read per 32 rows) and become FP4 +-1 values in registers (3 shifts + 4 v_and_or_b32 per 32 bits,
+// as in bowm.hip; the order of the 256 bit positions inside the product is free as long as both operands use the same one).
+// No staging instructions, no barrier, a quarter of the operand bytes; 28 more vector instructions per 32 candidate rows.
+__device__ __forceinline__ uint32_t bf_and_or(uint32_t x, uint32_t mask, uint32_t bits) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
+    return r;
+}
+__device__ __forceinline__ v8i bf_expand_fp4(uint32_t w, uint32_t ones) {
+    const uint32_t sign = 0x88888888u;
+    return (v8i){(int)bf_and_or(w << 3, sign, ones), (int)bf_and_or(w << 2, sign, ones), (int)bf_and_or(w << 1, sign, ones),
+                 (int)bf_and_or(w, sign, ones), 0, 0, 0, 0};
+}
+
+template <bool WANT_DIST, int NT>
+__global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__restrict__ table,
+                                                           const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
+                                                           int blocks_per_pair, float ratio, int th, int track_below, int stride,
+                                                           int32_t *__restrict__ match, int32_t *__restrict__ best_d,
+                                                           int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = bid / blocks_per_pair;
+    const int qb = bid - p * blocks_per_pair;
+    const FrameG A(table[fa[p]]), B(table[fb[p]]);
+    const int nA = A.n, nB = B.n;
+    constexpr int QW = 32 * NT;
+    if (qb * (4 * QW) >= nA) {
+        for (int i = threadIdx.x; i < 4 * QW; i += 256) if (qb * (4 * QW) + i < stride) match[(size_t)p * stride + qb * (4 * QW) + i] = -1;
+        return;
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
+    const int qbase = qb * (4 * QW) + wave * QW;
+    if (qbase >= nA) {                 // a wave without queries (no barrier in this kernel: it simply leaves)
+        for (int i = l; i < QW; i += 64) if (qbase + i < stride) match[(size_t)p * stride + qbase + i] = -1;
+        return;
+    }
+    uint32_t ones = 0x22222222u;
+    asm volatile("" : "+v"(ones));
+    v8i bq[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int row = min(qbase + t * 32 + col, max(nA - 1, 0));
+        const v4u x = ((gptr<const v4u>)A.desc)[2 * (size_t)row + h];
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int s = 0; s < 4; s++) bq[t][s] = bf_expand_fp4(w[s], ones);
+    }
+    uint32_t best[NT], second[NT];
+    float T[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        best[t] = (256u << 16) | 0xFFFFu;
+        second[t] = (256u << 16) | 0xFFFFu;
+        T[t] = (float)(256 - 2 * min(256, track_below));
+    }
+    const int one = 0x7F7F7F7F;
+    const gptr<const v4u> rowsB = (gptr<const v4u>)B.desc;
+    const int nB8 = (nB + 31) & ~31;
+    auto fetch = [&](int rb) -> v4u { return rowsB[2 * (size_t)min(rb + col, max(nB - 1, 0)) + h]; };   // rows past the end: the last row again (never ranked)
+    v4u nxt = nB8 > 0 ? fetch(0) : v4u{0, 0, 0, 0};
+    for (int rb = 0; rb < nB8; rb += 32) {
+        const v4u cur = nxt;
+        if (rb + 32 < nB8) nxt = fetch(rb + 32);
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        v16f acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const v8i a = bf_expand_fp4(w[s], ones);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one);
+        }
+        bool fire = false;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float m = fmaxf(fmaxf(acc[t][0], acc[t][1]), acc[t][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[t][r]), acc[t][r + 1]);
+            m = fmaxf(m, acc[t][15]);
+            fire = fire || m > T[t];
+        }
+        if (__any(fire)) {
+            const int cand0 = rb + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int cand = cand0 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const uint32_t key = cand < nB ? ((uint32_t)((256 - (int)acc[t][r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                    second[t] = umed3(best[t], second[t], key); best[t] = min(best[t], key);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) T[t] = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
+        }
+    }
+    int accepted = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const uint32_t pb = (uint32_t)__shfl_xor((int)best[t], 32), ps = (uint32_t)__shfl_xor((int)second[t], 32);
+        const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
+        const int qi = qbase + t * 32 + col;
+        if (h == 0 && qi < nA) {
+            const int bd = (int)(b >> 16), sd = (int)(s2 >> 16);
+            const int bidx = bd >= 256 ? -1 : (int)(b & 0xFFFFu);
+            int mm = -1;
+            if (bd <= th && (float)bd < __fmul_rn(ratio, (float)sd)) { mm = bidx; accepted++; }  // :304-308
+            const size_t o = (size_t)p * stride + qi;
+            match[o] = mm;
+            if (WANT_DIST) {
+                if (best_d) best_d[o] = bd;
+                if (second_d) second_d[o] = sd;
+            }
+        } else if (h == 0 && qi < stride) {
+            match[(size_t)p * stride + qi] = -1;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
+    if (l == 0 && accepted) atomicAdd(&counts[p], accepted);
+}
+
 int g_bf_variant = 0;
 
 }  // namespace
@@ -495,13 +620,16 @@ int g_bf_variant = 0;
 // tuning / diagnostic knob used by scripts/ (not part of the public ABI)
 extern "C" void orbm__bf2nn_variant(int v) { g_bf_variant = v; }
 
-// 0 = default: the MX-scaled FP4 MFMA form (10); 11 = the vector-ALU kernel; the rest are A/B and diagnostic forms
+// 0 = default (15): the FP4 MFMA form fed from the raw descriptor rows, query tiles per wave chosen by batch size (12: two,
+// 13: four, 14: one); 10 = the same product fed from pre-expanded FP4 images through LDS (ORBMATCH_BF2NN_KERNEL=lds);
+// 9 = int8 MFMA; 11 = the vector-ALU kernel (ORBMATCH_BF2NN_KERNEL=valu); the rest are A/B and diagnostic forms
 static int bf2nn_variant_in_use() {
     // opt-in at run time: ORBMATCH_BF2NN_EARLY_ABANDON=1 selects the early-abandon kernel (same results)
     static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
     // ORBMATCH_BF2NN_KERNEL=valu selects the vector-ALU xor + popcount kernel (no +-1 image of the frames is built)
     static const bool env_valu = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return e && !strcmp(e, "valu"); }();
-    return g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : 10;
+    static const int env_form = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return !e ? 0 : !strcmp(e, "lds") ? 10 : !strcmp(e, "raw2") ? 12 : !strcmp(e, "raw4") ? 13 : 0; }();
+    return g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : env_form ? env_form : 15;
 }
 
 extern "C" int orbm_bf2nn_prepare(orbm_ctx *ctx) {
@@ -579,6 +707,29 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         else if (best_d || second_d) MF4_LAUNCH(true, 0);
         else MF4_LAUNCH(false, 0);
 #undef MF4_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return io.finish();
+    }
+    if (variant >= 12 && variant <= 15) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
+        // 15: by batch size (scripts/bf_small_perf.py).  Four tiles per wave amortise the expansion of a candidate fragment over
+        // 16 MFMAs (3 waves per SIMD) and win from about a thousand 2000 x 2000 pairs; below that more, smaller
+        // workgroups fill the chip sooner: two tiles from 32 pairs, one tile for a handful (one pair alone: 24 us).
+        int nt = variant == 12 ? 2 : variant == 13 ? 4 : 1;
+        if (variant == 15) {
+            const long long wg4 = (long long)n_pairs * ((max_na + 511) / 512), wg2 = (long long)n_pairs * ((max_na + 255) / 256);
+            nt = wg4 >= 3000 ? 4 : wg2 >= 256 ? 2 : 1;
+        }
+        const int per_block = 4 * 32 * nt;
+        const int bpp = (max_na + per_block - 1) / per_block;
+        const long long gridr = (long long)n_pairs * bpp;
+        if (gridr > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
+#define MF4R_LAUNCH(WD, NTT)                                                                                                     \
+        hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT>), dim3((unsigned)gridr), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+                           (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
+        if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
+        else if (nt == 1) { if (best_d || second_d) MF4R_LAUNCH(true, 1); else MF4R_LAUNCH(false, 1); }
+        else { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }
+#undef MF4R_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         return io.finish();
     }

@@ -8,14 +8,14 @@ from orbslam2_amd.matcher import Context
 from orbslam2_amd import _lib
 torch.cuda.init(); dev = torch.device("cuda:0")
 ctx = Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-kfs, ids = bench.build_store(ctx, 20161011 + 2)
+kfs, ids = bench.build_store(ctx, 96)
 L = _lib.load()
 rng = np.random.default_rng(3)
 match = torch.empty((4096, bench.N_FEAT), dtype=torch.int32, device=dev); counts = torch.empty(4096, dtype=torch.int32, device=dev)
 for P in (1, 4, 16, 64, 256, 1024, 4096):
     fa, fb = bench.pair_list(rng, ids, P)
     tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
-    for variant, name in ((0, "mfma fp4"), (11, "valu")):
+    for variant, name in ((0, "default"), (10, "fp4 lds"), (14, "raw nt1"), (12, "raw nt2"), (13, "raw nt4"), (11, "valu")):
         L.orbm__bf2nn_variant(variant)
         best = 1e30
         for rep in range(6):

@@ -17,9 +17,10 @@ dev = torch.device("cuda:0")
 fa = torch.tensor(ids[pa], dtype=torch.int32, device=dev); fb = torch.tensor(ids[pb], dtype=torch.int32, device=dev)
 match = torch.empty((P, 2000), dtype=torch.int32, device=dev); counts = torch.empty(P, dtype=torch.int32, device=dev)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-names = {11: "R2U4", 1: "R4U2", 2: "R4U1", 3: "R2U2", 4: "R4U2-noupdate", 5: "R4U2-always", 6: "R4U4", 7: "R2U4-trackall", 8: "R2U4-early-abandon", 9: "MFMA-i8", 10: "MFMA-fp4-mx"}
+names = {11: "R2U4", 8: "R2U4-early-abandon", 9: "MFMA-i8", 10: "MFMA-fp4-mx", 12: "MFMA-fp4 raw rows, no LDS, 2 tiles", 13: "MFMA-fp4 raw rows, no LDS, 4 tiles"}
+if os.environ.get("ORBM_BF_ALL"): names.update({1: "R4U2", 2: "R4U1", 3: "R2U2", 4: "R4U2-noupdate", 5: "R4U2-always", 6: "R4U4", 7: "R2U4-trackall"})
 res = {v: [] for v in names}
-for rnd in range(5):
+for rnd in range(8):
     for v in names:
         L.orbm__bf2nn_variant(v)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -28,7 +29,7 @@ for rnd in range(5):
         e1.record(); torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1))
 ref = None
-for v in (11, 8, 9, 10):   # the early-abandon and MFMA variants must give the same matches
+for v in (11, 8, 9, 10, 12, 13):   # the early-abandon and MFMA variants must give the same matches
     L.orbm__bf2nn_variant(v)
     ctx.bf2nn_dev(P, fa.data_ptr(), fb.data_ptr(), 0.75, 50, 2000, match.data_ptr(), None, None, counts.data_ptr())
     torch.cuda.synchronize()

@@ -95,12 +95,14 @@ def test_bf2nn_batch_many_pairs(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     """The vector-ALU kernel (11) and its tile-shape variants, the track-everything variant, the opt-in early-abandon
-    variant (8: the last 64 bits of a comparison are skipped once the first 192 already reach the tracking bound) and the
-    int8 MFMA form (9) all return the reference's matches -- as does the default, the MX-scaled FP4 MFMA form, which every
-    other test of this file runs -- with and without the raw distances, across thresholds and ratios."""
+    variant (8: the last 64 bits of a comparison are skipped once the first 192 already reach the tracking bound), the
+    int8 MFMA form (9), the FP4 MFMA form fed from pre-expanded images through LDS (10) and the FP4 MFMA form fed from the
+    raw rows with two / four / one query tiles per wave (12 / 13 / 14; the default picks among these by batch size, which
+    every other test of this file runs) all return the reference's matches, with and without the raw distances, across
+    thresholds and ratios."""
     from orbslam2_amd import _lib
     L = _lib.load()
     kfs = synth.keyframe_pool(seed=78, n_kf=5, n=700, window=1000) + contended_frames(79)
