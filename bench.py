@@ -39,8 +39,8 @@ LIST_CAP = 1 << 21          # list entries per launch (8 MB); a diagonal-heavy l
 ACCEPT = 20                 # LoopClosing.cc:459
 RATIO, TH = 0.75, 50
 SMALL_KF = 96               # keyframes of the store that the secondary measurements and the CPU baseline use
-# The headline kernel computes Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA,
-# DESIGN.md section 4.1): one comparison = a 256-long dot product = 512 FLOP.  Dense FP4 peak: one
+# The headline kernel computes Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA fed from
+# the raw descriptor rows): one comparison = a 256-long dot product = 512 FLOP.  Dense FP4 peak: one
 # v_mfma_scale_f32_32x32x64_f8f6f4 (2 * 32 * 32 * 64 FLOP) per 32 cycles per SIMD, 256 CUs x 4 SIMDs @ 2.4 GHz
 FLOP_PER_CMP = 512.0
 PEAK_MFMA_TFLOPS = 256 * 4 * (2 * 32 * 32 * 64 / 32.0) * 2.4e9 / 1e12
@@ -228,15 +228,15 @@ def secondary(ctx, torch, dev, ids):
         if rep:
             best = min(best, e0.elapsed_time(e1))
     out["search_bow_kfkf_pairs_per_s"] = round(8192 / (best * 1e-3), 1)
-    # config 2 again with two more forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount with early
-    # abandon and the int8 MFMA form
+    # config 2 again with three more forms of the kernel (identical matches, tests/test_gpu_bf2nn.py): xor + popcount with early
+    # abandon, the int8 MFMA form and round 1's FP4 MFMA form (pre-expanded images staged through LDS)
     from orbslam2_amd import _lib
     L = _lib.load()
     P2 = 4096
     fa2, fb2 = pair_list(np.random.default_rng(11), ids, P2)
     tfa2 = torch.tensor(fa2, device=dev); tfb2 = torch.tensor(fb2, device=dev)
     m2 = torch.empty((P2, N_FEAT), dtype=torch.int32, device=dev); c2 = torch.empty(P2, dtype=torch.int32, device=dev)
-    for variant, name in ((8, "valu_early_abandon"), (9, "mfma_int8")):
+    for variant, name in ((8, "valu_early_abandon"), (9, "mfma_int8"), (10, "mfma_fp4_lds_staged")):
         try:
             L.orbm__bf2nn_variant(variant)
             best = 1e30
@@ -387,7 +387,7 @@ def main():
     n_kf = args.keyframes
     t_setup = time.perf_counter()
     kfs, ids = build_store(ctx, n_kf)                       # same store on every rank (replicated)
-    ctx.bf2nn_prepare()                                     # +-1 images of every keyframe: launches below only enqueue
+    ctx.bf2nn_prepare()                                     # a no-op for the default kernel (it reads the raw rows); builds the images of the other MFMA forms
     P, L = args.pairs, args.launches
     pa, pb = allpairs.shard_pairs(n_kf, rank, world, TILE)  # this rank's block-cyclic share of the triangle
     n_mine = len(pa)
@@ -520,7 +520,7 @@ def main():
             "setup_s": round(setup_s, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_MFMA_TFLOPS, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "bf2nn_mfma4_kernel<false,0,2>", "kernel_ms": round(kms, 4),
+                         "kernel": "bf2nn_mfma4r_kernel<false,4>", "kernel_ms": round(kms, 4),
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
                          "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
                                  "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "

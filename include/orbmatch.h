@@ -231,15 +231,16 @@ int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_
  * match[p*stride+i] = j or -1 (rows between the a-frame's n and the stride: -1, on both I/O paths); best_d / second_d
  * (nullable) get the raw distances (256 = none; their rows beyond n are not written);
  * counts[p] = accepted rows.  stride >= max n of the a-frames.
- * The distances are computed on the matrix cores from a +-1 image of each frame (128 B per descriptor, built on the
- * device the first time a frame is used here and released with the frame); results are identical to the xor + popcount
- * form, which the environment variable ORBMATCH_BF2NN_KERNEL=valu selects instead. */
+ * The distances are computed on the matrix cores (every descriptor bit as +-1 in FP4, expanded in registers from the
+ * frames' raw rows; exact) and are identical to the xor + popcount form, which the environment variable
+ * ORBMATCH_BF2NN_KERNEL=valu selects instead.  ORBMATCH_BF2NN_KERNEL=lds selects round 1's form of the same product, which
+ * keeps a pre-expanded image of each frame (128 B per descriptor, built on the device the first time a frame is used). */
 int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                      float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
                      int32_t *second_d, int32_t *counts, int io_on_device);
-/* Builds the +-1 images of every live frame NOW (one launch + one stream synchronisation).  Without it the first
- * orbm_bf2nn_batch call that meets a frame builds its image and synchronises; with io_on_device = 1 that first call builds
- * the images of ALL live frames.  After it, device-path calls only enqueue work (until new frames are uploaded). */
+/* Only for the forms that keep a +-1 image per frame (ORBMATCH_BF2NN_KERNEL=lds, the int8 form): builds the images of every
+ * live frame NOW (one launch + one stream synchronisation) instead of at the first orbm_bf2nn_batch call that meets a
+ * frame.  A no-op for the default kernel. */
 int orbm_bf2nn_prepare(orbm_ctx *ctx);
 
 /* ---- BASELINE config 5 / SURVEY 8(e): batched keyframe-pair matching that leaves COMPACT match records ----------------

@@ -6,7 +6,7 @@ set -e
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
-rm -rf $OUT && mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT   # (delete the local gpurun_out/prof_<tag> too before a re-run: results are merged into it)
 # counter passes: a smaller store (the triangle extras of the full store take minutes under counter collection)
 ARGS="bench.py --steps 4 --warmup 1 --keyframes 640 --no-cpu-baseline"
 ( while true; do sleep 50; echo "[profile_bench] $(date +%T) still running"; done ) &

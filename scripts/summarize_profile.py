@@ -9,7 +9,7 @@ with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-HEAD = "bf2nn_mfma4"      # the headline kernel (bench.py also runs the other forms once each, in `extra`)
+HEAD = "bf2nn_mfma4r"     # the headline kernel (bench.py also runs the other forms once each, in `extra`)
 def counters(sub, kern=HEAD):
     f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
     agg = collections.defaultdict(list)
@@ -25,7 +25,7 @@ for extra_pass in ("sq2", "sq3"):
         pass
 bf = [r for r in rows if HEAD in r["Name"]][0]
 P, N = int(os.environ.get("ORBM_PROF_PAIRS", "16384")), 2000     # pairs per orbm_allpairs_batch launch (bench.py PAIRS_PER_LAUNCH)
-alg_bytes = P * (2 * N * 128 + N * 4 + 4)     # both +-1 FP4 images (128 B per descriptor) once per pair + match row + count
+alg_bytes = P * (2 * N * 32 + N * 4 + 4)      # both frames' raw descriptor rows (32 B) once per pair + match row + count
 # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # 16-byte-per-lane coalesced reads (our staging and query loads) -> doubled
 hbm = (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024
