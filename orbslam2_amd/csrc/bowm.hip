@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         if (tid == 0 && nmatches) atomicAdd(&pair_acc[p * 32 + 30], nmatches);
         return;
     }
-    if (check_ori) {
+    const int found = nmatches;                           // read by every thread before anyone changes it (the barrier inside comes first)
+    if (check_ori && found > 0) {                         // a pair without matches has nothing to filter
         if (tid == 0) {
             int i1, i2, i3;
             three_maxima(hist, i1, i2, i3);
