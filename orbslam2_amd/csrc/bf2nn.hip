@@ -337,9 +337,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma_kernel(const FrameDev *__restr
     if (l == 0 && accepted) atomicAdd(&counts[p], accepted);
 }
 
-// ---- MX-scaled FP4 form ------------------------------------------------------------------------------------------------
+// ---- FP4 form ----------------------------------------------------------------------------------------------------------
 // The same product with the +-1 values as FP4 E2M1 (FrameDev::desc4, 128 B per row) through
-// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0): K = 64 per instruction at the cycles of the bf16 32x32 form, so a
+// v_mfma_f32_32x32x64_f8f6f4 (the builtin with zero scale operands selects the unscaled 8-byte encoding, block scale 2^0;
+// the scaled encoding with explicit 2^0 scales is a second instruction word and measured 2.5 % slower): K = 64 per instruction at the cycles of the bf16 32x32 form, so a
 // tile of 1024 distances is 4 instructions instead of 8, and every staged byte carries two bit positions.  (The 16x16x128
 // shape of the same instruction was measured 12 % slower here, 8-wave workgroups and register-prefetched stages no
 // faster; scripts/ubench_mfma4*.hip: what the chip sustains on this instruction and what each ingredient of this loop costs.)  Products are
@@ -392,7 +393,6 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
         second[t] = (256u << 16) | 0xFFFFu;
         T[t] = (float)(256 - 2 * min(256, track_below));
     }
-    const int one = 0x7F7F7F7F;        // E8M0 block scale 2^0 in every byte
 
     const gptr<const v4i> Bd4 = (gptr<const v4i>)B.desc4;
     // Two LDS buffers of MF4_ROWS / 2 rows; the next stage travels global -> LDS directly (global_load_lds, no registers)
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
                 const v4i x = arow[(2 * s + h) ^ ((col >> 1) & 7)];
                 const v8i a = {x[0], x[1], x[2], x[3], 0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one);
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, 0, 0, 0);
             }
             bool fire = false;
             float msum = 0.f;
@@ -505,7 +505,8 @@ __device__ __forceinline__ v8i bf_expand_fp4(uint32_t w, uint32_t ones) {
                  (int)bf_and_or(w, sign, ones), 0, 0, 0, 0};
 }
 
-template <bool WANT_DIST, int NT>
+// PIPE: 0 plain, 1 with s_setprio around the products (+3..4 % sustained: the matrix pipe idles less), 10-12 timing diagnostics
+template <bool WANT_DIST, int NT, int PIPE = 0>
 __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__restrict__ table,
                                                            const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
                                                            int blocks_per_pair, float ratio, int th, int track_below, int stride,
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         for (int i = l; i < QW; i += 64) if (qbase + i < stride) match[(size_t)p * stride + qbase + i] = -1;
         return;
     }
+    const long long diag_c0 = PIPE == 10 ? clock64() : 0, diag_w0 = PIPE == 10 ? wall_clock64() : 0;
     uint32_t ones = 0x22222222u;
     asm volatile("" : "+v"(ones));
     v8i bq[NT][4];
@@ -539,41 +541,70 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         for (int s = 0; s < 4; s++) bq[t][s] = bf_expand_fp4(w[s], ones);
     }
     uint32_t best[NT], second[NT];
-    float T[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         best[t] = (256u << 16) | 0xFFFFu;
         second[t] = (256u << 16) | 0xFFFFu;
-        T[t] = (float)(256 - 2 * min(256, track_below));
     }
     const int one = 0x7F7F7F7F;
     const gptr<const v4u> rowsB = (gptr<const v4u>)B.desc;
     const int nB8 = (nB + 31) & ~31;
     auto fetch = [&](int rb) -> v4u { return rowsB[2 * (size_t)min(rb + col, max(nB - 1, 0)) + h]; };   // rows past the end: the last row again (never ranked)
+    // bound per tile as integer bits; a bound below zero (more than 128 differing bits still relevant: only until the second
+    // best falls below that) sends every block through the exact path
+    int Ti[NT];
+    bool anyneg = false;
+    auto set_bounds = [&]() {
+        bool neg = false;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float Tf = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
+            Ti[t] = Tf >= 0.f ? __float_as_int(Tf) : (int)0x80000000;
+            neg = neg || Tf < 0.f;
+        }
+        anyneg = __any(neg);
+    };
+    set_bounds();
     v4u nxt = nB8 > 0 ? fetch(0) : v4u{0, 0, 0, 0};
+    v4u nxt2 = nB8 > 32 ? fetch(32) : nxt;          // candidate rows are requested two blocks ahead
     for (int rb = 0; rb < nB8; rb += 32) {
+        if (PIPE == 1 || PIPE == 3) __builtin_amdgcn_s_setprio(1);       // a wave that has matrix instructions to issue goes before waves that are ranking
         const v4u cur = nxt;
-        if (rb + 32 < nB8) nxt = fetch(rb + 32);
+        nxt = nxt2;
+        if (rb + 64 < nB8) nxt2 = fetch(rb + 64);
         const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
         v16f acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const v8i a = bf_expand_fp4(w[s], ones);
+            const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0} : bf_expand_fp4(w[s], ones);   // 10-12: timing diagnostics (results are wrong)
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one);
+            for (int t = 0; t < NT; t++)
+                acc[t] = PIPE == 3 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one)   // A/B: the scaled encoding
+                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, 0, 0, 0);
         }
+        if (PIPE == 10 || PIPE == 12) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#ifdef __HIP_DEVICE_COMPILE__
+                asm volatile("" ::"v"(acc[t]));
+#endif
+            }
+            continue;
+        }
+        if (PIPE == 1 || PIPE == 3) __builtin_amdgcn_s_setprio(0);
+        // dot products are ranked as integers (a positive float orders like its bits, every negative float is a negative
+        // integer): eight v_max3_i32 per tile fold its sixteen values and the bound
         bool fire = false;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            float m = fmaxf(fmaxf(acc[t][0], acc[t][1]), acc[t][2]);
+            int m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[t][r]), acc[t][r + 1]);
-            m = fmaxf(m, acc[t][15]);
-            fire = fire || m > T[t];
+            for (int r = 2; r < 16; r += 2) m = max(max(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
+            fire = fire || m != Ti[t];
         }
-        if (__any(fire)) {
+        if (anyneg || __any(fire)) {
             const int cand0 = rb + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -584,9 +615,13 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
                     second[t] = umed3(best[t], second[t], key); best[t] = min(best[t], key);
                 }
             }
-#pragma unroll
-            for (int t = 0; t < NT; t++) T[t] = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
+            set_bounds();
         }
+    }
+    if (PIPE == 10) {          // diagnostic: the shader clock this wave saw, in MHz (wall_clock64 ticks at 100 MHz)
+        const long long dc = clock64() - diag_c0, dw = wall_clock64() - diag_w0;
+        if (l == 0 && wave == 0 && qb == 0) match[(size_t)p * stride] = (int32_t)(dc * 100 / max(dw, 1LL));
+        return;
     }
     int accepted = 0;
 #pragma unroll
@@ -710,11 +745,11 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         HIPCHK(ctx, hipGetLastError());
         return io.finish();
     }
-    if (variant >= 12 && variant <= 15) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
+    if (variant >= 12 && variant <= 20) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
         // 15: by batch size (scripts/bf_small_perf.py).  Four tiles per wave amortise the expansion of a candidate fragment over
         // 16 MFMAs (3 waves per SIMD) and win from about a thousand 2000 x 2000 pairs; below that more, smaller
         // workgroups fill the chip sooner: two tiles from 32 pairs, one tile for a handful (one pair alone: 24 us).
-        int nt = variant == 12 ? 2 : variant == 13 ? 4 : 1;
+        int nt = variant == 12 ? 2 : variant == 13 || variant >= 16 ? 4 : 1;
         if (variant == 15) {
             const long long wg4 = (long long)n_pairs * ((max_na + 511) / 512), wg2 = (long long)n_pairs * ((max_na + 255) / 256);
             nt = wg4 >= 3000 ? 4 : wg2 >= 256 ? 2 : 1;
@@ -723,12 +758,17 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         const int bpp = (max_na + per_block - 1) / per_block;
         const long long gridr = (long long)n_pairs * bpp;
         if (gridr > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
-#define MF4R_LAUNCH(WD, NTT)                                                                                                     \
-        hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT>), dim3((unsigned)gridr), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+#define MF4R_LAUNCH(WD, NTT, ...)                                                                                                \
+        hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT, ##__VA_ARGS__>), dim3((unsigned)gridr), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
-        if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
+        if (variant == 13) { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }     // A/B: without s_setprio
+        else if (variant == 16) { if (best_d || second_d) MF4R_LAUNCH(true, 4, 3); else MF4R_LAUNCH(false, 4, 3); }
+        else if (variant == 18) MF4R_LAUNCH(false, 4, 10);
+        else if (variant == 19) MF4R_LAUNCH(false, 4, 11);
+        else if (variant == 20) MF4R_LAUNCH(false, 4, 12);
+        else if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
         else if (nt == 1) { if (best_d || second_d) MF4R_LAUNCH(true, 1); else MF4R_LAUNCH(false, 1); }
-        else { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }
+        else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }
 #undef MF4R_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         return io.finish();

@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     const int thr = MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW;          // :304 / :792
     const float Tf = (float)(256 - 2 * capd);                          // dot > Tf  <=>  distance < capd
-    const int one = 0x7F7F7F7F;                                        // E8M0 block scale 2^0 in every byte
     uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
     asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 // dots are 0 = distance 128, never below capd, so no record can name a row that does not exist
                 const uint32_t liveq = qa0 + (uint32_t)col < nAs ? ones : 0u, livec = cb0 + (uint32_t)col < nBs ? ones : 0u;
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s], livec), expand_fp4(wq[s], liveq), acc, 4, 4, 0, one, 0, one);
+                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s], livec), expand_fp4(wq[s], liveq), acc, 4, 4, 0, 0, 0, 0);   // zero scale operands select the unscaled encoding (one 8-byte instruction)
                 float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);

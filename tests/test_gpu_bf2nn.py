@@ -95,7 +95,7 @@ def test_bf2nn_batch_many_pairs(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     """The vector-ALU kernel (11) and its tile-shape variants, the track-everything variant, the opt-in early-abandon
     variant (8: the last 64 bits of a comparison are skipped once the first 192 already reach the tracking bound), the
