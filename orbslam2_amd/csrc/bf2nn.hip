@@ -22,6 +22,7 @@
 //     only fires for candidates that can matter.  All nA x nB distances are still evaluated.
 // Candidate rows are staged global -> LDS in coalesced 16-byte loads, TILE rows at a time; all lanes read
 // the same LDS row (broadcast ds_read_b128 x2) and reuse it for their R queries.
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -565,6 +566,10 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         anyneg = __any(neg);
     };
     set_bounds();
+    // NL = the wave's tiles that hold queries (wave-uniform; the last wave of a 2000-row frame has three of four): tiles
+    // without queries cost no products
+    auto scan = [&](auto nl_tag) {
+    constexpr int NL = decltype(nl_tag)::value;
     v4u nxt = nB8 > 0 ? fetch(0) : v4u{0, 0, 0, 0};
     v4u nxt2 = nB8 > 32 ? fetch(32) : nxt;          // candidate rows are requested two blocks ahead
     for (int rb = 0; rb < nB8; rb += 32) {
@@ -575,18 +580,18 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
         v16f acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < NL; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0} : bf_expand_fp4(w[s], ones);   // 10-12: timing diagnostics (results are wrong)
 #pragma unroll
-            for (int t = 0; t < NT; t++)
+            for (int t = 0; t < NL; t++)
                 acc[t] = PIPE == 3 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one)   // A/B: the scaled encoding
                                    : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, 0, 0, 0);
         }
         if (PIPE == 10 || PIPE == 12) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
+            for (int t = 0; t < NL; t++) {
 #ifdef __HIP_DEVICE_COMPILE__
                 asm volatile("" ::"v"(acc[t]));
 #endif
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         // integer): eight v_max3_i32 per tile fold its sixteen values and the bound
         bool fire = false;
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
+        for (int t = 0; t < NL; t++) {
             int m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
 #pragma unroll
             for (int r = 2; r < 16; r += 2) m = max(max(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
             for (int r = 0; r < 16; r++) {
                 const int cand = cand0 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
+                for (int t = 0; t < NL; t++) {
                     const uint32_t key = cand < nB ? ((uint32_t)((256 - (int)acc[t][r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
                     second[t] = umed3(best[t], second[t], key); best[t] = min(best[t], key);
                 }
@@ -618,6 +623,12 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
             set_bounds();
         }
     }
+    };
+    const int nl = min(NT, (nA - qbase + 31) >> 5);
+    if (nl == NT) scan(std::integral_constant<int, NT>{});
+    else if (NT > 2 && nl == 3) scan(std::integral_constant<int, (NT > 2 ? 3 : 1)>{});
+    else if (NT > 1 && nl == 2) scan(std::integral_constant<int, (NT > 1 ? 2 : 1)>{});
+    else scan(std::integral_constant<int, 1>{});
     if (PIPE == 10) {          // diagnostic: the shader clock this wave saw, in MHz (wall_clock64 ticks at 100 MHz)
         const long long dc = clock64() - diag_c0, dw = wall_clock64() - diag_w0;
         if (l == 0 && wave == 0 && qb == 0) match[(size_t)p * stride] = (int32_t)(dc * 100 / max(dw, 1LL));
