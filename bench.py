@@ -520,7 +520,7 @@ def main():
             "setup_s": round(setup_s, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_MFMA_TFLOPS, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "bf2nn_mfma4r_kernel<false,4>", "kernel_ms": round(kms, 4),
+                         "kernel": "bf2nn_mfma4r_kernel<false,4,1>", "kernel_ms": round(kms, 4),
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
                          "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
                                  "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "
