@@ -41,7 +41,7 @@ RATIO, TH = 0.75, 50
 SMALL_KF = 96               # keyframes of the store that the secondary measurements and the CPU baseline use
 # The headline kernel computes Hamming distances as exact +-1 dot products on the matrix cores (MX-scaled FP4 MFMA fed from
 # the raw descriptor rows): one comparison = a 256-long dot product = 512 FLOP.  Dense FP4 peak: one
-# v_mfma_scale_f32_32x32x64_f8f6f4 (2 * 32 * 32 * 64 FLOP) per 32 cycles per SIMD, 256 CUs x 4 SIMDs @ 2.4 GHz
+# v_mfma_f32_32x32x64_f8f6f4 (2 * 32 * 32 * 64 FLOP) per 32 cycles per SIMD, 256 CUs x 4 SIMDs @ 2.4 GHz
 FLOP_PER_CMP = 512.0
 PEAK_MFMA_TFLOPS = 256 * 4 * (2 * 32 * 32 * 64 / 32.0) * 2.4e9 / 1e12
 # integer-popcount roofline of the vector-ALU kernel (reported beside it): per wave64 comparison one SIMD must issue
@@ -500,7 +500,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp4-mx (+-1 per descriptor bit, exact) x fp4-mx -> f32 accumulate (exact integers)", "data": "synthetic",
+            "dtype": "fp4 e2m1 (+-1 per descriptor bit, exact) x fp4 e2m1 -> f32 accumulate (exact integers)", "data": "synthetic",
             "config": {"workload": "brute-force 2-NN Hamming + TH_LOW + ratio test, 2000x2000 256-bit descriptors per keyframe pair "
                                    "(BASELINE configs[1]), batched over the pair triangle of the config-5 store (BASELINE configs[4])",
                        "store_keyframes": n_kf, "features_per_keyframe": N_FEAT, "pairs_in_triangle": n_kf * (n_kf - 1) // 2,
@@ -523,7 +523,7 @@ def main():
                          "kernel": "bf2nn_mfma4r_kernel<false,4,1>", "kernel_ms": round(kms, 4),
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
                          "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
-                                 "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_scale_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "
+                                 "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "
                                  "kernel_ms = HIP events around one orbm_allpairs_batch call on its stream, averaged over the timed "
                                  "region: the matching kernel plus its counter memset and the two record-compaction kernels "
                                  "(profiles/: < 1 % of it), so `achieved` is a slight under-statement of the kernel alone. traffic: "
