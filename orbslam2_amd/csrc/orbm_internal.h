@@ -291,8 +291,9 @@ __device__ __forceinline__ bool check_dist_epipolar_line(float x1, float y1, flo
 __device__ __forceinline__ void three_maxima(const int *sizes, int &ind1, int &ind2, int &ind3) {
     // (size << 8 | 255 - bin) keys: a larger size ranks first, the lower bin index among equal sizes (strict '>' in a
     // scan by ascending bin); sizes of 0 never rank (the reference starts from max = 0 with strict '>')
+    // fully unrolled: the 30 reads are issued together (a rolled loop waits for each one: 2 us instead of 0.3)
     uint32_t k1 = 0, k2 = 0, k3 = 0;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
         const int s = sizes[i];
         uint32_t x = s > 0 ? ((uint32_t)s << 8) | (uint32_t)(255 - i) : 0u, hi;

@@ -124,6 +124,39 @@ def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     ctx.free_frames(ids)
 
 
+@pytest.mark.parametrize("variant", [0, 12, 13, 14])
+def test_bf2nn_tile_boundaries_mixed_sizes(ctx, orc, variant):
+    """Frames of every size around the 32-row tile and the 128 / 256 / 512-row workgroup boundaries, mixed in ONE launch
+    (a wave's number of live query tiles, the last candidate block and the rows between a frame's n and the stride all
+    differ from pair to pair), through the raw-row MFMA forms with one / two / four query tiles per wave and the default
+    choice, with and without raw distances; padding entries of the match rows must read -1."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4242)
+    lm = synth.random_descriptors(rng, 700)
+    sizes = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 257, 383, 385, 511, 512, 513, 640]
+    frames = [synth.make_frame(rng, lm, rng.permutation(700)[:n], with_fv=False, p_flip=0.06) for n in sizes]
+    ids = ctx.upload_frames(frames)
+    k = len(sizes)
+    pa, pb = np.meshgrid(np.arange(k), np.arange(k))
+    pa, pb = pa.ravel(), pb.ravel()
+    stride = 656        # not a multiple of 32, above the largest frame
+    try:
+        L.orbm__bf2nn_variant(variant)
+        for want_dist in (False, True):
+            counts, match, bd, sd = ctx.bf2nn(ids[pa], ids[pb], 0.8, 60, stride=stride, want_dist=want_dist)
+            for q, (i, j) in enumerate(zip(pa, pb)):
+                wc, wm, wbd, wsd, _ = orc.bf2nn(frames[i], frames[j], 0.8, 60)
+                n = frames[i].n
+                assert counts[q] == wc and np.array_equal(match[q, :n], wm), (variant, want_dist, sizes[i], sizes[j])
+                assert (match[q, n:] == -1).all(), (variant, want_dist, sizes[i], sizes[j])
+                if want_dist:
+                    assert np.array_equal(bd[q, :n], wbd) and np.array_equal(sd[q, :n], wsd), (variant, sizes[i], sizes[j])
+    finally:
+        L.orbm__bf2nn_variant(0)
+    ctx.free_frames(ids)
+
+
 def contended_frames(seed):
     """Frames re-observing a small landmark pool with little noise: many near-ties around the thresholds."""
     rng = np.random.default_rng(seed)
