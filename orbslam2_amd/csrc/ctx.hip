@@ -568,6 +568,7 @@ static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     struct Offs { size_t desc, f0, f1, f2, f3, angle, l0, l1, flags; bool has_f3, has_angle; };
     std::vector<Offs> offs(n_sets);
+    std::vector<uint32_t> packed;
     Packer pk;
     for (int k = 0; k < n_sets; k++) {
         Offs &o = offs[k];
@@ -580,11 +581,15 @@ static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, 
             for (size_t i = 0; i < n; i++)
                 if (q.level[i] < 0 || q.level[i] >= ORBM_MAX_LEVELS) return orbm_fail(ctx, ORBM_EINVAL, "query set %d: level[%zu] out of range", k, i);
             o.desc = pk.add(q.desc, n * 32);
-            o.f0 = pk.add(q.proj_x, n * 4); o.f1 = pk.add(q.proj_y, n * 4); o.f2 = pk.add(q.proj_xr, n * 4);
-            o.f3 = pk.add(q.view_cos, n * 4); o.has_f3 = true; o.has_angle = false; o.angle = 0;
-            o.l0 = pk.add(q.level, n * 4); o.l1 = o.l0;
-            o.flags = pk.add(q.flags, n);
-            if (!q.flags) memset(pk.host.data() + o.flags, ORBM_Q_VALID | ORBM_Q_OBS, n);
+            // the six parameter arrays become one 16-byte record per query (QSetDev::pk)
+            packed.resize(4 * n);
+            for (size_t i = 0; i < n; i++) {
+                memcpy(&packed[4 * i], &q.proj_x[i], 4); memcpy(&packed[4 * i + 1], &q.proj_y[i], 4); memcpy(&packed[4 * i + 2], &q.proj_xr[i], 4);
+                const uint32_t fl = q.flags ? q.flags[i] : (uint32_t)(ORBM_Q_VALID | ORBM_Q_OBS);
+                packed[4 * i + 3] = (uint32_t)q.level[i] | (fl << 8) | (q.view_cos[i] >= 0.998f ? 1u << 16 : 0u);   // ORBmatcher.cc:168-174
+            }
+            o.f0 = pk.add(packed.data(), n * 16);
+            o.f1 = o.f2 = o.f3 = o.l0 = o.l1 = o.flags = 0; o.has_f3 = false; o.has_angle = false; o.angle = 0;
         } else {
             const orbm_win_queries &q = wsets[k];
             if (q.n < 0) return orbm_fail(ctx, ORBM_EINVAL, "query set %d: n < 0", k);
@@ -615,11 +620,15 @@ static int upload_qsets(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *ps, 
         q.n = ps ? ps[k].n : wsets[k].n;
         q.kind = ps ? 0 : 1;
         q.desc = (const uint32_t *)(b + o.desc);
-        q.f0 = (const float *)(b + o.f0); q.f1 = (const float *)(b + o.f1); q.f2 = (const float *)(b + o.f2);
-        q.f3 = o.has_f3 ? (const float *)(b + o.f3) : nullptr;
-        q.angle = o.has_angle ? (const float *)(b + o.angle) : nullptr;
-        q.l0 = (const int32_t *)(b + o.l0); q.l1 = (const int32_t *)(b + o.l1);
-        q.flags = (const uint8_t *)(b + o.flags);
+        if (ps) {
+            q.pk = (const uint32_t *)(b + o.f0);
+        } else {
+            q.f0 = (const float *)(b + o.f0); q.f1 = (const float *)(b + o.f1); q.f2 = (const float *)(b + o.f2);
+            q.f3 = o.has_f3 ? (const float *)(b + o.f3) : nullptr;
+            q.angle = o.has_angle ? (const float *)(b + o.angle) : nullptr;
+            q.l0 = (const int32_t *)(b + o.l0); q.l1 = (const int32_t *)(b + o.l1);
+            q.flags = (const uint8_t *)(b + o.flags);
+        }
         int32_t id;
         if (!ctx->free_qsets.empty()) { id = ctx->free_qsets.back(); ctx->free_qsets.pop_back(); ctx->h_qsets[id] = q; ctx->qset_arena[id] = arena_id; }
         else { id = (int32_t)ctx->h_qsets.size(); ctx->h_qsets.push_back(q); ctx->qset_arena.push_back(arena_id); }

@@ -48,6 +48,10 @@ struct QSetDev {
     const float *angle;               // kind1 only, may be null
     const int32_t *l0, *l1;           // kind0: level, - | kind1: min_level, max_level
     const uint8_t *flags;
+    // kind0 only, and then the ONLY per-query parameters on the device (f0..f3, l0, flags are null): 16 bytes per query
+    // {proj_x, proj_y, proj_xr, level | flags << 8 | (view_cos >= 0.998f) << 16}, so that a query gathered by index costs
+    // one load instead of six
+    const uint32_t *pk;
 };
 
 struct Arena {
@@ -231,10 +235,11 @@ struct QSetG {
     gptr<const float> f0, f1, f2, f3, angle;
     gptr<const int32_t> l0, l1;
     gptr<const uint8_t> flags;
+    gptr<const uint32_t> pk;
     QSetG() = default;
     __device__ __forceinline__ explicit QSetG(const QSetDev &q)
         : n(q.n), kind(q.kind), desc(in_global(q.desc)), f0(in_global(q.f0)), f1(in_global(q.f1)), f2(in_global(q.f2)),
-          f3(in_global(q.f3)), angle(in_global(q.angle)), l0(in_global(q.l0)), l1(in_global(q.l1)), flags(in_global(q.flags)) {}
+          f3(in_global(q.f3)), angle(in_global(q.angle)), l0(in_global(q.l0)), l1(in_global(q.l1)), flags(in_global(q.flags)), pk(in_global(q.pk)) {}
 };
 
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {

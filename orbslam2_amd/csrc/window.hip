@@ -135,26 +135,30 @@ __device__ __forceinline__ Query load_params(const WinParams &P, const FrameG &F
             q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
             q.angle = S.F1.angle[qi];
         }
+    } else if (MODE == MODE_PROJ) {
+        // one 16-byte record per query (QSetDev::pk): x, y, xr, level | flags << 8 | (viewCos >= 0.998f) << 16.  :168-174
+        // compares the float viewCos with the double 0.998: true exactly for floats >= 0.998f (0x3F7F7CEE, whose value lies
+        // above 0.998; the float below it lies below); the upload evaluates it
+        const v4u k = ((gptr<const v4u>)S.QS.pk)[qi];
+        q.flags = (k.w >> 8) & 0xFFu;
+        if (q.flags & ORBM_Q_VALID) {
+            q.valid = true;
+            q.x = __uint_as_float(k.x); q.y = __uint_as_float(k.y); q.xr = __uint_as_float(k.z);
+            const int lvl = (int)(k.w & 0xFFu);
+            float rv = ((k.w >> 16) & 1u) ? 2.5f : 4.0f;
+            if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                              // :61, :84-85
+            q.r = __fmul_rn(rv, F.sf[lvl]);                                          // :89
+            q.minL = lvl - 1; q.maxL = lvl;
+        }
     } else {
         const QSetG &QS = S.QS;
         q.flags = QS.flags[qi];
         if (q.flags & ORBM_Q_VALID) {
             q.valid = true;
             q.x = QS.f0[qi]; q.y = QS.f1[qi];
-            if (MODE == MODE_PROJ) {
-                const int lvl = QS.l0[qi];
-                // :168-174 compares the float viewCos with the double 0.998: true exactly for floats >= 0.998f (0x3F7F7CEE,
-                // whose value lies above 0.998; the float below it lies below)
-                float rv = (QS.f3[qi] >= 0.998f) ? 2.5f : 4.0f;
-                if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                          // :61, :84-85
-                q.r = __fmul_rn(rv, F.sf[lvl]);                                      // :89
-                q.minL = lvl - 1; q.maxL = lvl;
-                q.xr = QS.f2[qi];
-            } else {
-                q.r = QS.f2[qi]; q.minL = QS.l0[qi]; q.maxL = QS.l1[qi];
-                if (QS.f3) q.xr = QS.f3[qi];
-                if (QS.angle) q.angle = QS.angle[qi];
-            }
+            q.r = QS.f2[qi]; q.minL = QS.l0[qi]; q.maxL = QS.l1[qi];
+            if (QS.f3) q.xr = QS.f3[qi];
+            if (QS.angle) q.angle = QS.angle[qi];
         }
     }
     return q;
@@ -165,12 +169,14 @@ template <int MODE>
 __device__ __forceinline__ float load_radius(const WinParams &P, const FrameG &F, const QSrc &S, int qi) {
     if (qi >= S.Q) return -1.f;
     if (MODE == MODE_INIT) return S.F1.octave[qi] == 0 ? (float)P.window : -1.f;
-    if (!(S.QS.flags[qi] & ORBM_Q_VALID)) return -1.f;
     if (MODE == MODE_PROJ) {
-        float rv = (S.QS.f3[qi] >= 0.998f) ? 2.5f : 4.0f;
+        const uint32_t w = S.QS.pk[4 * (size_t)qi + 3];
+        if (!((w >> 8) & ORBM_Q_VALID)) return -1.f;
+        float rv = ((w >> 16) & 1u) ? 2.5f : 4.0f;
         if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);
-        return __fmul_rn(rv, F.sf[S.QS.l0[qi]]);
+        return __fmul_rn(rv, F.sf[w & 0xFFu]);
     }
+    if (!(S.QS.flags[qi] & ORBM_Q_VALID)) return -1.f;
     return S.QS.f2[qi];
 }
 
@@ -242,7 +248,7 @@ __device__ __forceinline__ int word_tail(uint32_t head2, uint32_t head3) {
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt) {
+                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt, int cost_exact) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[COLLECT_THREADS / 64];
@@ -335,12 +341,40 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (h >= groups || tid >= qt) { cls[h] = 0; rank[h] = 0; continue; }
-            // cost class = the window's area in cells, from its half-size alone (no window arithmetic here)
-            const float rr = load_radius<MODE>(P, F, S, sc * SUPER + h * qt + tid);
+            // cost class = the trip count of the query's walk below: the records of its runs plus one per coarse column
+            // (the window arithmetic and the run bounds are computed here as well as there; exact classes keep the lanes
+            // of a wave together, a class by window area left 46 % of them idle)
             int c = 0;
-            if (rr >= 0.f) {
-                const int area = (int)((2.f * rr * inv_w + 2.f) * (2.f * rr * inv_h + 2.f));
-                c = area < 124 ? 1 + (max(area, 0) >> 1) : min(COST_CLASSES - 1, 62 + ((area - 124) >> 6));
+            if (cost_exact & 1) {
+                const Query q = load_params<MODE>(P, F, S, sc * SUPER + h * qt + tid);
+                if (q.valid) {
+                    const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
+                    const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
+                    const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
+                    const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
+                    const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
+                    int lo = -1, hi = 255;
+                    if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
+                    else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+                    int st = 0;
+                    bool covered = !pairs;
+                    if (pairs && hi <= 7 && hi >= 0 && hi - lo <= 1) { st = hi; covered = true; }
+                    if (covered && x1 >= x0 && y1 >= y0) {
+                        const int k = s_k[st], sb = s_base[st];
+                        int trip = 1;
+                        for (int X = x0 >> k; X <= (x1 >> k); X++) {
+                            const int b = sb + X * ORBM_GRID_ROWS;
+                            trip += 1 + (int)c_off[b + y1 + 2] - (int)c_off[b + y0 + 1];
+                        }
+                        c = trip < 48 ? trip : min(COST_CLASSES - 1, 48 + ((trip - 48) >> 4));
+                    }
+                }
+            } else {
+                const float rr = load_radius<MODE>(P, F, S, sc * SUPER + h * qt + tid);
+                if (rr >= 0.f) {
+                    const int area = (int)((2.f * rr * inv_w + 2.f) * (2.f * rr * inv_h + 2.f));
+                    c = area < 124 ? 1 + (max(area, 0) >> 1) : min(COST_CLASSES - 1, 62 + ((area - 124) >> 6));
+                }
             }
             cls[h] = c;
             rank[h] = atomicAdd(&l_bucket[c], 1);
@@ -363,7 +397,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             l_perm[l_bucket[cls[h]] + rank[h]] = (uint16_t)(h * qt + tid);
         }
         __syncthreads();
-      for (int h = 0; h < groups && wave < QW; h++) {
+      for (int h = 0; h < groups && wave < QW && !(cost_exact & 8); h++) {
         const int group = h == 0 ? wave : 2 * QW - 1 - wave;
         const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
         Query q = load_params<MODE>(P, F, S, qi);
@@ -384,7 +418,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         bool uncovered = false;
         uint32_t *mytail = tail_out + ((size_t)inst * qstride + min(qi, (int)qstride - 1)) * tcap;
         // first phase: a single flat loop over the runs of the window's coarse columns
-        if (q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0) {
+        if (!(cost_exact & 2) && q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0) {   // (bits 1-3 of cost_exact: timing diagnostics)
             // the structure of the octave pair {hi-1, hi} holds every octave of [lo, hi] when hi - lo <= 1; a wider (or
             // open) range can only come with the one-structure index
             int st = 0;
@@ -428,7 +462,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         // second phase: Hamming distances, wave-uniform trip count; the four smallest words sorted, the others to the tail
         uint32_t k0 = W_INVALID, k1 = W_INVALID, k2 = W_INVALID, k3 = W_INVALID;
         {
-            const int nhave = min(ncand, tcap + 4);
+            const int nhave = (cost_exact & 4) ? 0 : min(ncand, tcap + 4);
             int wn = nhave;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wn = max(wn, __shfl_xor(wn, off, 64));
@@ -999,6 +1033,7 @@ static size_t collect_lds_bytes(const CoarseCfg &c) {
 // tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
 // 2 = single kernel reading the frame from global memory
 int g_win_variant = 0;
+int g_win_cost_exact = 1;   // cost classes of collect_kernel: 1 = the walk's exact trip count, 0 = window area (A/B knob)
 
 template <int MODE>
 int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int max_q, int max_levels) {
@@ -1053,7 +1088,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
         const size_t lds = collect_lds_bytes(cfg);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt);
+                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
         return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail, tcap);
@@ -1132,6 +1167,7 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
 
 // tuning / test knob (not part of the public ABI): see g_win_variant
 extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
+extern "C" void orbm__window_cost_exact(int v) { g_win_cost_exact = v; }
 
 extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
                                              float th, float ratio, const uint8_t *slot_flags, int32_t stride,

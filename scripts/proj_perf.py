@@ -26,14 +26,20 @@ owner = torch.empty((n_inst, 2000), dtype=torch.int32, device=dev); cnt = torch.
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 bytes_inst = 50000 * (32 + 20 + 1) + 2000 * 49 + 3073 * 4 + 2000 * 4
 THS = [float(t) for t in os.environ.get("ORBM_TH", "1,3,5,8").split(",")]
-for th in THS:
-    ts = []
-    for rep in range(4):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ctx.search_proj_points_dev(n_inst, tfr.data_ptr(), tqs.data_ptr(), th, 0.8, None, 2000, owner.data_ptr(), cnt.data_ptr())
-        e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ms = min(ts[1:])
-    print("th=%.0f  %d inst: %.3f ms  %.2f G queries/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  matches/inst=%d" % (
-        th, n_inst, ms, n_inst * 50000 / ms / 1e6, n_inst * bytes_inst / ms / 1e6, n_inst * bytes_inst / ms / 1e6 / 80.0, int(cnt[0])))
+from orbslam2_amd import _lib
+_L = _lib.load()
+COSTS = [int(c) for c in os.environ.get("ORBM_WIN_COST", "1").split(",")]     # 1 = exact trip-count classes, 0 = window area
+for cost in COSTS:
+  _L.orbm__window_cost_exact(cost)
+  print("cost classes:", "exact trip count" if cost else "window area")
+  for th in THS:
+      ts = []
+      for rep in range(4):
+          e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+          e0.record()
+          ctx.search_proj_points_dev(n_inst, tfr.data_ptr(), tqs.data_ptr(), th, 0.8, None, 2000, owner.data_ptr(), cnt.data_ptr())
+          e1.record(); torch.cuda.synchronize()
+          ts.append(e0.elapsed_time(e1))
+      ms = min(ts[1:])
+      print("th=%.0f  %d inst: %.3f ms  %.2f G queries/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)  matches/inst=%d" % (
+          th, n_inst, ms, n_inst * 50000 / ms / 1e6, n_inst * bytes_inst / ms / 1e6, n_inst * bytes_inst / ms / 1e6 / 80.0, int(cnt[0])))
