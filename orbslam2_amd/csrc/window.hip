@@ -248,7 +248,7 @@ __device__ __forceinline__ int word_tail(uint32_t head2, uint32_t head3) {
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt, int cost_exact) {
+                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt, int cost_exact, int desc_lds) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[COLLECT_THREADS / 64];
@@ -258,11 +258,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const int total = cfg.base[cfg.nstruct];                                     // buckets
     const int offn = (total + 6) & ~1;                                           // u16 entries of c_off (see below), even
     uint16_t *c_off = reinterpret_cast<uint16_t *>(lds);
-    v4f *c_rec = reinterpret_cast<v4f *>(lds + ((offn / 2 + 3) & ~3));
-    uint16_t *l_idx = reinterpret_cast<uint16_t *>(c_rec + cfg.rec_cap);          // stream position -> keypoint index
-    uint16_t *l_cc = l_idx + ((cfg.n_cap + 7) & ~7);                             // PARK x COLLECT_THREADS record positions
+    v4f *c_rec = reinterpret_cast<v4f *>(lds + ((offn / 2 + 3) & ~3));           // one record per stream position
+    uint16_t *c_lst = reinterpret_cast<uint16_t *>(c_rec + ((cfg.n_cap + 3) & ~3));   // the buckets' runs: stream positions
+    uint16_t *l_cc = c_lst + ((cfg.rec_cap + 7) & ~7);                           // PARK x COLLECT_THREADS stream positions
     int *l_bucket = (int *)(l_cc + PARK * COLLECT_THREADS);                      // cost classes
     uint16_t *l_perm = reinterpret_cast<uint16_t *>(l_bucket + COST_CLASSES);    // 2 x COLLECT_THREADS
+    v4u *l_desc = reinterpret_cast<v4u *>(l_perm + 2 * COLLECT_THREADS + 32);    // desc_lds: the frame's descriptors in stream order
     if (tid < 8) s_k[tid] = cfg.kshift[tid];
     if (tid < 9) s_base[tid] = cfg.base[tid];
     // ---- the index.  Bucket b's run is c_rec[c_off[b + 1] .. c_off[b + 2]): counters sit at c_off[b + 2] (two u16 per
@@ -279,7 +280,6 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     for (int j = tid; j < T; j += COLLECT_THREADS) {
         const uint32_t w = __float_as_uint(F.cell_rec[j].w);
         const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
-        l_idx[j] = (uint16_t)(w & 0xFFFFu);
         if (pairs) {
             if (oct <= 7) bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy);
             if (oct + 1 <= 7) bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy);
@@ -311,12 +311,17 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         const v4f rc = F.cell_rec[j];
         const uint32_t w = __float_as_uint(rc.w);
         const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
-        const v4f mine = {rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17))};
+        c_rec[j] = v4f{rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17))};
         if (pairs) {
-            if (oct <= 7) c_rec[bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy)] = mine;
-            if (oct + 1 <= 7) c_rec[bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy)] = mine;
+            if (oct <= 7) c_lst[bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy)] = (uint16_t)j;
+            if (oct + 1 <= 7) c_lst[bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy)] = (uint16_t)j;
         } else {
-            c_rec[bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy)] = mine;
+            c_lst[bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy)] = (uint16_t)j;
+        }
+        if (desc_lds) {                      // the candidates' descriptors are read from LDS, by stream position
+            const int kp = (int)(w & 0xFFFFu);
+            const gptr<const v4u> gd = (gptr<const v4u>)F.desc;
+            l_desc[2 * j] = gd[2 * kp]; l_desc[2 * j + 1] = gd[2 * kp + 1];
         }
     }
     __syncthreads();
@@ -432,8 +437,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             uncovered = !covered;                                // cannot happen with the launch rules below; if it does: re-walk
             while (more) {
                 if (j < e) {
-                    const uint32_t jcur = j;
-                    const v4f rc = c_rec[j];
+                    const uint32_t jcur = c_lst[j];               // stream position of the run's next record
+                    const v4f rc = c_rec[jcur];
                     j++;
                     const uint32_t w = __float_as_uint(rc.w);
                     const int oct = (int)((w >> 13) & 15u), cx = (int)(w >> 17);
@@ -471,9 +476,10 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
                 if (i < nhave) {
                     const uint32_t pos = i < PARK ? (uint32_t)l_cc[i * COLLECT_THREADS + tid] : mytail[i - 4];
                     const uint32_t w = __float_as_uint(c_rec[pos].w);
-                    const uint32_t j13 = w & 0x1FFFu;
-                    const int kp = (int)l_idx[j13];
-                    const v4u dlo = gdesc[2 * kp], dhi = gdesc[2 * kp + 1];
+                    const uint32_t j13 = pos;
+                    v4u dlo, dhi;
+                    if (desc_lds) { dlo = l_desc[2 * pos]; dhi = l_desc[2 * pos + 1]; }
+                    else { const int kp = (int)F.cell_idx[pos]; dlo = gdesc[2 * kp]; dhi = gdesc[2 * kp + 1]; }
                     const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
                     uint32_t x = (hamming256(qd, cd) << 17) | (j13 << 4) | ((w >> 13) & 15u), t;
                     t = min(k0, x); x = max(k0, x); k0 = t;
@@ -501,6 +507,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
 template <int MODE, bool LDS_FRAME, bool PRE>
 __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const uint32_t *tail_in, int tcap) {
     extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ int s_any[3];
     const int inst = blockIdx.x;
     const FrameG F(P.frames[P.frame_ids[inst]]);
     const int n = F.n;
@@ -550,6 +557,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     if (MODE == MODE_INIT) for (int i = tid; i < Q; i += nthr) out[i] = -1;              // vnMatches12 (:566)
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) *nmatch = 0;
+    if (tid < 3) s_any[tid] = 0;            // wg_any's flags (below)
     __syncthreads();
 
     const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
@@ -573,6 +581,17 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
         return __builtin_amdgcn_readfirstlane(v);
+    };
+    // "does any thread of the workgroup ...?" with ONE barrier (__syncthreads_or is three): three flags in rotation; the one
+    // used next is cleared by thread 0 before this call's barrier (its last readers passed the previous barrier already)
+    int any_phase = 0;
+    auto wg_any = [&](bool pred) {
+        const int cur = any_phase % 3;
+        if (pred) s_any[cur] = 1;
+        if (tid == 0) s_any[(any_phase + 1) % 3] = 0;
+        __syncthreads();
+        any_phase++;
+        return s_any[cur] != 0;
     };
     auto is_blocked = [&](uint32_t st, int dist) {
         if (MODE == MODE_PROJ || MODE == MODE_LAST) return (st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS);   // :113-115 / :1879-1881
@@ -642,7 +661,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             }
             unresolved = live;
         }
-        if (!__syncthreads_or(unresolved ? 1 : 0)) return;
+        if (!wg_any(unresolved)) return;
 
         int round = 0;
         while (true) {
@@ -705,7 +724,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                 contested = post[bestIdx] < (uint32_t)tid;
                 if (USES_SECOND && bestIdx2 >= 0 && post[bestIdx2] < (uint32_t)tid) contested = true;
             }
-            if (__syncthreads_or(contested ? 1 : 0)) {
+            if (wg_any(contested)) {
                 if (contested) {
                     if (cached) {
                         for (int i = 0; i < wave_ncand; i++) {
@@ -777,7 +796,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             }
             // the other post buffer is idle in this phase (decide only reads `post`): clear it for the next round
             for (int i = tid; i < n_slots; i += nthr) post_next[i] = NOPOST;
-            if (!__syncthreads_or(unresolved ? 1 : 0)) break;
+            if (!wg_any(unresolved)) break;
             round++;
         }
         // leave both post buffers clean for the next chunk
@@ -835,10 +854,17 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                 if (live) lm |= 1u << u;
             }
             __syncthreads();
-            if (tid < SCAN_U * NW) {
-                int sum = 0;
-                for (int e2 = 0; e2 < tid; e2++) sum += cnts[e2];
-                pre[tid] = sum;
+            if (tid < 64) {                                                  // exclusive prefix over the SCAN_U x NW (<= 128) counts, one wave
+                const int a = 2 * tid < SCAN_U * NW ? cnts[2 * tid] : 0, b = 2 * tid + 1 < SCAN_U * NW ? cnts[2 * tid + 1] : 0;
+                int incl = a + b;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d, 64);
+                    if (tid >= d) incl += up;
+                }
+                const int excl = incl - (a + b);
+                if (2 * tid < SCAN_U * NW) pre[2 * tid] = excl;
+                if (2 * tid + 1 < SCAN_U * NW) pre[2 * tid + 1] = excl + a;
             }
             __syncthreads();
 #pragma unroll
@@ -1021,13 +1047,14 @@ static CoarseCfg coarse_cfg(bool pairs, const float *rmax_px, int max_n) {
     return c;
 }
 
-// dynamic LDS of collect_kernel: bucket offsets (u16), index records, stream position -> keypoint (u16), parking (u16),
-// cost classes, lane assignment (u16)
-static size_t collect_lds_bytes(const CoarseCfg &c) {
+// dynamic LDS of collect_kernel: bucket offsets (u16), one record per stream position, the buckets' runs (u16 stream
+// positions), parking (u16), cost classes, lane assignment (u16) and, when it fits (frames up to ~2100 keypoints), the
+// frame's descriptors in stream order
+static size_t collect_lds_bytes(const CoarseCfg &c, bool desc_lds) {
     const int total = c.base[c.nstruct];
     const size_t offn = (size_t)((total + 6) & ~1);
-    return (((offn / 2 + 3) & ~(size_t)3)) * 4 + (size_t)c.rec_cap * 16 + (size_t)((c.n_cap + 7) & ~7) * 2 +
-           (size_t)PARK * COLLECT_THREADS * 2 + COST_CLASSES * 4 + 2 * COLLECT_THREADS * 2 + 64;
+    return (((offn / 2 + 3) & ~(size_t)3)) * 4 + (size_t)((c.n_cap + 3) & ~3) * 16 + (size_t)((c.rec_cap + 7) & ~7) * 2 +
+           (size_t)PARK * COLLECT_THREADS * 2 + COST_CLASSES * 4 + 2 * COLLECT_THREADS * 2 + 64 + (desc_lds ? (size_t)c.n_cap * 32 + 16 : 0);
 }
 
 // tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
@@ -1050,7 +1077,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     if (!PAIRS) rmax[0] = 20.0f;
     const CoarseCfg cfg = coarse_cfg(PAIRS, rmax, max_n);
     // frames too large for collect_kernel's LDS index (or with more than 8 pyramid levels) use the single-kernel form
-    const bool single = g_win_variant != 0 || collect_lds_bytes(cfg) > 160 * 1024 || max_n > 8191 || (PAIRS && max_levels > 8);
+    const bool single = g_win_variant != 0 || collect_lds_bytes(cfg, false) > 160 * 1024 || max_n > 8191 || (PAIRS && max_levels > 8);
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
             return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr);
@@ -1085,10 +1112,11 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
             qt = (int)std::min<long long>(COLLECT_THREADS, std::max<long long>(64, (per_wg + 63) / 64 * 64));
             wgs_per_inst = std::max(1, (waves_per_inst * 64 + qt - 1) / qt);
         }
-        const size_t lds = collect_lds_bytes(cfg);
+        const bool desc_lds = collect_lds_bytes(cfg, true) <= 160 * 1024 && !(g_win_cost_exact & 32);
+        const size_t lds = collect_lds_bytes(cfg, desc_lds);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
         hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact);
+                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact, desc_lds ? 1 : 0);
         HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
         return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail, tcap);
