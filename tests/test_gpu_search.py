@@ -395,6 +395,22 @@ def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
         L.orbm__window_variant(0)
 
 
+@pytest.mark.parametrize("n", [2040, 2100, 2124, 2160, 3300, 4900, 5300, 6500, 8100])
+def test_proj_points_across_the_lds_layout_boundaries(ctx, orc, n):
+    """collect_kernel keeps the frame's descriptors in LDS up to ~2100 keypoints, reads them from global memory above that,
+    and hands over to the single-kernel forms when its index no longer fits: frame sizes on both sides of each boundary
+    (th 1 and th 5 size the bucket structures differently), alone and mixed with a small frame in the same launch."""
+    f, q = synth.proj_instance(seed=7000 + n, n=n, n_queries=4000, claimed_frac=0.1, obs_frac=0.7, stereo=(n % 2 == 0))
+    f2, q2 = synth.proj_instance(seed=7001 + n, n=300, n_queries=900, claimed_frac=0.1, obs_frac=0.7)
+    fid = ctx.upload_frames([f, f2]); qid = ctx.upload_proj_queries([q, q2])
+    for th in (1.0, 5.0):
+        counts, owner = ctx.search_proj_points(fid, qid, th, 0.8, stride=n)
+        for k, (ff, qq) in enumerate(((f, q), (f2, q2))):
+            wc, wo, _ = orc.search_proj_points(ff, qq, th, 0.8)
+            assert counts[k] == wc and np.array_equal(owner[k, :ff.n], wo), (n, th, k)
+    ctx.free_frames(fid); ctx.free_queries(qid)
+
+
 def test_frames_over_the_window_limit_are_rejected(ctx):
     from orbslam2_amd.matcher import OrbmError
     f, q = synth.proj_instance(seed=903, n=9000, n_queries=10)
