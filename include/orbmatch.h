@@ -135,6 +135,9 @@ int orbm_frame_set_mp_flags(orbm_ctx *ctx, int32_t id, const uint8_t *mp_flags);
 /* copies the device-built grid back: cell_off[ORBM_GRID_CELLS+1], cell_idx[n]; cell = ix*48+iy */
 int orbm_frame_grid_download(orbm_ctx *ctx, int32_t id, uint32_t *cell_off, uint32_t *cell_idx);
 
+/* query sets of SearchByProjection(F, vpMapPoints, th): device copy = the descriptors (32 B per query) + ONE 16-byte
+ * record per query {proj_x, proj_y, proj_xr, level | flags << 8 | (view_cos >= 0.998f) << 16} (the comparison of
+ * ORBmatcher.cc:168-174 is evaluated here; a search gathers a query with one load).  48 bytes per query in HBM. */
 int orbm_proj_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_proj_queries *sets, int32_t *out_ids);
 int orbm_win_queries_upload(orbm_ctx *ctx, int n_sets, const orbm_win_queries *sets, int32_t *out_ids);
 int orbm_queries_free(orbm_ctx *ctx, int n_sets, const int32_t *ids);
