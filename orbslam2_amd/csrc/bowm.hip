@@ -401,11 +401,13 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 const uint32_t liveq = qa0 + (uint32_t)col < nAs ? ones : 0u, livec = cb0 + (uint32_t)col < nBs ? ones : 0u;
 #pragma unroll
                 for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s], livec), expand_fp4(wq[s], liveq), acc, 4, 4, 0, 0, 0, 0);   // zero scale operands select the unscaled encoding (one 8-byte instruction)
-                float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+                // folded as integers (Tf >= 0: a positive float orders like its bits, a negative one is a negative integer):
+                // v_max3_i32 takes MFMA results as they are, fmaxf canonicalises each one first
+                int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
 #pragma unroll
-                for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
-                m = fmaxf(m, acc[15]);
-                if (__any(m > Tf)) {
+                for (int r = 3; r < 15; r += 2) m = max(max(m, __float_as_int(acc[r])), __float_as_int(acc[r + 1]));
+                m = max(m, __float_as_int(acc[15]));
+                if (__any(m > __float_as_int(Tf))) {
                     // the lane holds query qa0 + col against candidates cb0 + (r & 3) + 8 (r >> 2) + 4 h
                     const uint32_t qbits = (qa0 + (uint32_t)col) << 20, t0 = cb0 + (uint32_t)(4 * h);
 #pragma unroll
