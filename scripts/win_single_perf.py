@@ -10,6 +10,7 @@ from orbslam2_amd.matcher import Context, _addr
 
 ctx = Context(0)
 L = _lib.load()
+L.orbm__window_variant(int(os.environ.get('ORBM_WIN_VARIANT', '0')))   # 0 split (collect + claims), 1 one kernel with the frame in LDS, 2 one kernel from global memory
 for nq in (1000, 1500):
     f, q = synth.window_instance(11, 0, n=2000, n_queries=nq, th=7.0)
     fid = ctx.upload_frames([f])
