@@ -118,6 +118,17 @@ def cpu_baseline(kfs, n_store):
     def proj(k, r):
         orc.search_proj_points(f, q, 3.0, 0.8); return 1
     proj_inst_s, _ = _all_cores(proj, cores, 2.0)
+    proj_th = {}
+    for thv in (1.0, 5.0):                                   # Tracking.cc:1549-1560 calls with th 1, 3 or 5
+        t1 = time.perf_counter(); _, _, nc = orc.search_proj_points(f, q, thv, 0.8); proj_th[thv] = ((time.perf_counter() - t1) * 1e3, nc)
+    # C1: SearchForInitialization, 2 x 1000 keypoints, window 100, ratio 0.9 (Tracking.cc:768-769), one core: us / call, the
+    # reference's Hamming evaluations per call (the oracle's counter) and the match count
+    i1, i2, iprev = synth.init_pair()
+    c1_cnt, _, _, c1_cmps = orc.search_init(i1, i2, iprev, 100, 0.9, True)
+    t1 = time.perf_counter(); c1_n = 0
+    while time.perf_counter() - t1 < 1.0:
+        orc.search_init(i1, i2, iprev, 100, 0.9, True); c1_n += 1
+    c1_us = (time.perf_counter() - t1) * 1e6 / c1_n
     # C4: SearchByBoW(KF,KF) over the pair list `extra.search_bow_kfkf_*` runs: one core (time + the reference's distance
     # evaluations per pair, the oracle's counter), then all cores, one pair per task
     ia, ib = pair_list(np.random.default_rng(3), np.arange(nk), 8192)
@@ -165,6 +176,11 @@ def cpu_baseline(kfs, n_store):
             "search_by_projection_single_instance_ms": round(proj_ms, 3),
             "search_by_projection_all_cores_instances_per_s": round(proj_inst_s, 1),
             "search_by_projection_all_cores_queries_per_s": round(proj_inst_s * 50000, 1),
+            "search_by_projection_th1_single_instance_ms": round(proj_th[1.0][0], 3), "search_by_projection_th1_cmps": proj_th[1.0][1],
+            "search_by_projection_th5_single_instance_ms": round(proj_th[5.0][0], 3), "search_by_projection_th5_cmps": proj_th[5.0][1],
+            "c1_search_init_us_per_call": round(c1_us, 2), "c1_search_init_cmps_per_call": c1_cmps, "c1_search_init_matches": c1_cnt,
+            "c1_search_init_Gcmps": round(c1_cmps / c1_us / 1e3, 4),
+            "c1_note": "BASELINE config 1: SearchForInitialization, 2 frames x 1000 keypoints, 640x480, window 100, ratio 0.9, checkOri, one core",
             "search_bow_kfkf_ms_per_pair": round(bow_pair_ms, 4), "search_bow_kfkf_cmps_per_pair": round(bow_cmps / 256, 1),
             "search_bow_kfkf_all_cores_pairs_per_s": round(bow_pairs_s, 1),
             "c5_all_pairs_search_bow_all_cores_pairs_per_s": round(c5_bow_s, 1),
@@ -176,6 +192,22 @@ def cpu_baseline(kfs, n_store):
             "sample": f"{int(multi_pairs)} random keyframe pairs of the store's first {nk} keyframes ({N_FEAT}x{N_FEAT} brute-force 2-NN, SWAR popcount "
                       f"as ORBmatcher.cc:2184-2200), {cores} threads x 8 s ('generous CPU': the reference runs a matcher call on one thread); "
                       f"single thread {n1} pairs"}
+
+
+def measured_traffic(n_kf, pairs):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 counter pass (FETCH_SIZE / WRITE_SIZE in
+    their own runs, corrected as MI355X_MICROARCH.md prescribes; scripts/profile_bench.sh + summarize_profile.py): counters
+    cannot be read from inside this run, so the line quotes the pass taken on the SAME store size and launch size."""
+    import glob
+    hit = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bf2nn_traffic.json"))):
+        try:
+            d = json.load(open(fn))
+        except Exception:
+            continue
+        if d.get("store_keyframes") == n_kf and d.get("pairs_per_launch") == pairs:
+            hit = (d, os.path.relpath(fn, ROOT))
+    return hit
 
 
 def popcount_form(ctx, torch, dev, ids):
@@ -265,36 +297,53 @@ def secondary(ctx, torch, dev, ids):
     # config 3: SearchByProjection (th = 3), 50k map points into a 2000-keypoint frame.  Batch of instances with
     # distinct query sets (permutations of one set, so the queries really stream from HBM), then one instance alone.
     from orbslam2_amd.views import ProjQueries
-    n_inst, n_sets, NQ = 256, 64, 50000
+    n_inst, n_sets, NQ = 256, 256, 50000
     f, q = synth.proj_instance(seed=synth.SEED0 + 3, n=N_FEAT, n_queries=NQ)
     prng = np.random.default_rng(0)
     sets = []
-    for k in range(n_sets):
+    for k in range(n_sets):                                  # 256 distinct sets = 0.68 GB of queries: more than the 256 MB Infinity Cache
         p = prng.permutation(q.n)
         sets.append(ProjQueries(desc=q.desc[p], proj_x=q.proj_x[p], proj_y=q.proj_y[p], proj_xr=q.proj_xr[p], level=q.level[p],
                                 view_cos=q.view_cos[p], flags=q.flags[p]))
     fid = ctx.upload_frames([f] * 8); qid = ctx.upload_proj_queries(sets)
+    del sets
     tfr = torch.tensor(np.resize(fid, n_inst), device=dev); tqs = torch.tensor(np.resize(qid, n_inst), device=dev)
     owner = torch.empty((n_inst, N_FEAT), dtype=torch.int32, device=dev); cnt = torch.empty(n_inst, dtype=torch.int32, device=dev)
     # algorithmic bytes per instance: per query 32 B descriptor + 5 words + flag, the frame (49 B / keypoint + grid), owner out
     bytes_inst = NQ * (32 + 20 + 1) + N_FEAT * 49 + 3073 * 4 + N_FEAT * 4
-    for ni in (n_inst, 1):
+    for thv, ni in ((3.0, n_inst), (3.0, 1), (1.0, n_inst), (5.0, n_inst)):
         best = 1e30
         for rep in range(4):
             e0, e1 = ev(), ev(); e0.record()
-            ctx.search_proj_points_dev(ni, tfr.data_ptr(), tqs.data_ptr(), 3.0, 0.8, None, N_FEAT, owner.data_ptr(), cnt.data_ptr())
+            ctx.search_proj_points_dev(ni, tfr.data_ptr(), tqs.data_ptr(), thv, 0.8, None, N_FEAT, owner.data_ptr(), cnt.data_ptr())
             e1.record(); torch.cuda.synchronize()
             if rep:
                 best = min(best, e0.elapsed_time(e1))
+        tag = "" if thv == 3.0 else f"_th{int(thv)}"
         if ni > 1:
-            out["search_by_projection_queries_per_s"] = round(ni * NQ / (best * 1e-3), 1)
-            out["search_by_projection_algorithmic_GBps"] = round(ni * bytes_inst / (best * 1e-3) / 1e9, 1)
-            out["search_by_projection_hbm_frac"] = round(ni * bytes_inst / (best * 1e-3) / 8e12, 4)
-            out["search_by_projection_note"] = (f"{ni} instances x {NQ} queries -> 2000-kp frame per launch, th=3, {n_sets} distinct query "
-                                                f"sets; {bytes_inst} algorithmic bytes per instance; 8 TB/s HBM peak")
+            out[f"search_by_projection{tag}_queries_per_s"] = round(ni * NQ / (best * 1e-3), 1)
+            out[f"search_by_projection{tag}_algorithmic_GBps"] = round(ni * bytes_inst / (best * 1e-3) / 1e9, 1)
+            out[f"search_by_projection{tag}_hbm_frac"] = round(ni * bytes_inst / (best * 1e-3) / 8e12, 4)
+            out[f"search_by_projection{tag}_batch_ms"] = round(best, 4)
+            if thv == 3.0:
+                out["search_by_projection_note"] = (f"{ni} instances x {NQ} queries -> 2000-kp frame per launch, th=3 (_th1 / _th5: th = 1 / 5), {n_sets} "
+                                                    f"distinct query sets; {bytes_inst} algorithmic bytes per instance; 8 TB/s HBM peak")
         else:
             out["search_by_projection_single_instance_ms"] = round(best, 4)
     ctx.free_frames(fid); ctx.free_queries(qid)
+    # config 1: SearchForInitialization, 2 x 1000 keypoints, window 100 (host lists in and out: a single call as Tracking.cc:768 makes it)
+    i1, i2, iprev = synth.init_pair()
+    iid = ctx.upload_frames([i1, i2])
+    best = 1e30
+    for rep in range(6):
+        ctx.synchronize(); t0 = time.perf_counter()
+        c1 = ctx.search_init(iid[0], iid[1], iprev, 100, 0.9, True)[0]
+        dt1 = time.perf_counter() - t0
+        if rep:
+            best = min(best, dt1)
+    out["c1_search_init_ms"] = round(best * 1e3, 4)
+    out["c1_search_init_matches"] = int(c1)
+    ctx.free_frames(iid)
     # ComputeBoW on the device: descent of a k = 10, depth-6 tree (ORBvoc.txt's shape, 1.1 M nodes, synthetic) with every
     # descriptor of 96 keyframes + FeatureVector build, in one call; then one frame alone.  (Runs last: it replaces the
     # FeatureVectors of these keyframes with those of the synthetic tree.)
@@ -345,6 +394,35 @@ def full_triangle(ctx, torch, dev, fa_all, fb_all, pid_all, summ, lists, kind):
     return dt, int(acc), int(tot)
 
 
+def self_launch(argv, n_gpus):
+    """`python3 bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run (one per
+    GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  This process never touches the GPU (no torch import, no
+    orbm_create): the ranks are children, never an exec of a process that holds a device."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                      # the ranks' stderr goes straight through; stdout is relayed, the JSON line kept
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stdout.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        raise SystemExit(rc if rc != 0 else 1)
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,7 +433,12 @@ def main():
     ap.add_argument("--keyframes", type=int, default=STORE_KF)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="ranks only rendezvous (gloo, no GPU) and rank 0 prints how many it saw: the CPU test of the self-launch branch")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)      # does not return
 
     import torch
     import torch.distributed as dist
@@ -367,6 +450,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_probe:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([rank], dtype=torch.int64)
+            seen = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(seen, t)
+            ranks = sorted(int(x.item()) for x in seen)
+            dist.barrier(); dist.destroy_process_group()
+        else:
+            ranks = [0]
+        if rank == 0:
+            print(json.dumps({"metric": "launch-probe", "n_gpus": world, "ranks_seen": len(ranks), "ranks": ranks}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     # rehearsal only: ORBM_BENCH_BACKEND=gloo lets N ranks share one GPU (records hop through host memory)
@@ -484,9 +581,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # what every rank did, as rank 0 sees it through the process group: proof that N ranks took part
+    mine = torch.tensor([rank, P * L * args.steps, n_mine, dev_index], dtype=torch.int64, device=comm_dev)
+    if world > 1:
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        per_rank = [[int(v) for v in t.cpu().tolist()] for t in seen]
+        ranks_seen = dist.get_world_size()
+    else:
+        per_rank = [[int(v) for v in mine.cpu().tolist()]]
+        ranks_seen = 1
     kms = float(np.mean([a.elapsed_time(b) for a, b in kern_ev])) if kern_ev else float("nan")
     cmps_per_launch = float(P) * N_FEAT * N_FEAT
-    pairs_total = float(P) * L * args.steps * world
+    pairs_total = float(sum(p_[1] for p_ in per_rank))
     if rank == 0:
         achieved_tcmps = cmps_per_launch / (kms * 1e-3) / 1e12
         achieved = achieved_tcmps * FLOP_PER_CMP
@@ -511,7 +618,10 @@ def main():
                                       if world > 1 else "1 GPU (rank 0's shard = the whole triangle)"},
             "pairs_per_s": round(pairs_total / dt, 1),
             "timed_region_s": round(dt, 4),
-            "records": {"pairs_received": n_valid, "matches_in_summaries": matches_seen, "list_entries_received": sink["entries"],
+            "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (1 rank)",
+            "records": {"ranks_seen": ranks_seen,
+                        "per_rank": [{"rank": r, "pairs_timed": p_, "shard_pairs": s_, "device": d_} for r, p_, s_, d_ in per_rank],
+                        "pairs_received": n_valid, "matches_in_summaries": matches_seen, "list_entries_received": sink["entries"],
                         "bytes_over_the_wire": sink["bytes_wire"],
                         "wire_bytes_per_remote_pair": round(sink["bytes_wire"] / max(1, n_valid * (world - 1) / world), 2) if world > 1 else 0.0,
                         "record_bytes_per_pair": round((8 * n_valid + 4 * sink["entries"]) / max(1, n_valid), 2),
@@ -532,6 +642,12 @@ def main():
                                  "form of this kernel (roofline_popcount_form: that form, same run)"},
         }
         res["roofline"]["vs_integer_popcount_roofline"] = round(achieved_tcmps / PEAK_TCMPS, 3)
+        tr = measured_traffic(n_kf, P)
+        if tr:
+            res["roofline"]["traffic"] = round(tr[0]["hbm_bytes_per_launch"], 1)
+            res["roofline"]["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes)"
+            res["roofline"]["traffic_source"] = tr[1]
+            res["roofline"]["traffic_vs_naive"] = round(tr[0]["hbm_bytes_per_launch"] / (P * (2.0 * N_FEAT * 32 + N_FEAT * 4 + 4)), 4)
         small = ids[:SMALL_KF]
         try:
             res["roofline_popcount_form"] = popcount_form(ctx, torch, dev, small)

@@ -7,6 +7,9 @@ from .views import CBowVecView, CFrameView, CProjQueries, CVocabView, CWinQuerie
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbmatch_hip.so")
+# scripts/ only: ORBM_DIAG_LIB=1 loads the build with the timing diagnostics compiled in (`make -C orbslam2_amd/csrc diag`)
+if os.environ.get("ORBM_DIAG_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "liborbmatch_hip_diag.so")
 
 # every symbol include/orbmatch.h declares
 SYMBOLS = [

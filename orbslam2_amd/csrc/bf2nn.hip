@@ -663,8 +663,15 @@ int g_bf_variant = 0;
 
 }  // namespace
 
-// tuning / diagnostic knob used by scripts/ (not part of the public ABI)
-extern "C" void orbm__bf2nn_variant(int v) { g_bf_variant = v; }
+// tuning knob used by tests/ and scripts/ (not part of the public ABI).  Every form selectable in the release library returns
+// the same matches; the timing diagnostics that do not (4, 18-20, ORBM_MFMA_DIAG) exist only in builds with -DORBM_DIAG
+// (`make diag` -> liborbmatch_hip_diag.so, for scripts/), and a request for one of them selects the default form here.
+extern "C" void orbm__bf2nn_variant(int v) {
+#ifndef ORBM_DIAG
+    if (v == 4 || (v >= 18 && v <= 20)) v = 0;
+#endif
+    g_bf_variant = v;
+}
 
 // 0 = default (15): the FP4 MFMA form fed from the raw descriptor rows, query tiles per wave chosen by batch size (12: two,
 // 13: four, 14: one); 10 = the same product fed from pre-expanded FP4 images through LDS (ORBMATCH_BF2NN_KERNEL=lds);
@@ -744,13 +751,16 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         const int bpp9 = (max_na + per_block - 1) / per_block;
         const long long grid9 = (long long)n_pairs * bpp9;
         if (grid9 > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
-        static const int diag10 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
 #define MF4_LAUNCH(WD, DG)                                                                                                       \
         hipLaunchKernelGGL((bf2nn_mfma4_kernel<WD, DG, MF4_NT>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
+#ifdef ORBM_DIAG
+        static const int diag10 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
         if (diag10 == 1) MF4_LAUNCH(false, 1);
         else if (diag10 == 2) MF4_LAUNCH(false, 2);
-        else if (best_d || second_d) MF4_LAUNCH(true, 0);
+        else
+#endif
+        if (best_d || second_d) MF4_LAUNCH(true, 0);
         else MF4_LAUNCH(false, 0);
 #undef MF4_LAUNCH
         HIPCHK(ctx, hipGetLastError());
@@ -774,9 +784,11 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
                            (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
         if (variant == 13) { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }     // A/B: without s_setprio
         else if (variant == 16) { if (best_d || second_d) MF4R_LAUNCH(true, 4, 3); else MF4R_LAUNCH(false, 4, 3); }
+#ifdef ORBM_DIAG
         else if (variant == 18) MF4R_LAUNCH(false, 4, 10);
         else if (variant == 19) MF4R_LAUNCH(false, 4, 11);
         else if (variant == 20) MF4R_LAUNCH(false, 4, 12);
+#endif
         else if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
         else if (nt == 1) { if (best_d || second_d) MF4R_LAUNCH(true, 1); else MF4R_LAUNCH(false, 1); }
         else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }
@@ -788,6 +800,7 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         const int bpp9 = (max_na + 255) / 256;
         const long long grid9 = (long long)n_pairs * bpp9;
         if (grid9 > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
+#ifdef ORBM_DIAG
         static const int diag9 = [] { const char *e = getenv("ORBM_MFMA_DIAG"); return e ? atoi(e) : 0; }();
         if (diag9 == 1)
             hipLaunchKernelGGL((bf2nn_mfma_kernel<false, 1>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
@@ -795,7 +808,9 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         else if (diag9 == 2)
             hipLaunchKernelGGL((bf2nn_mfma_kernel<false, 2>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
                                (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
-        else if (best_d || second_d)
+        else
+#endif
+        if (best_d || second_d)
             hipLaunchKernelGGL((bf2nn_mfma_kernel<true, 0>), dim3((unsigned)grid9), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,
                                (const int32_t *)dfb, bpp9, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc);
         else
@@ -816,7 +831,9 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         case 1: BF_LAUNCH(4, 2, 0); break;
         case 2: BF_LAUNCH(4, 1, 0); break;
         case 3: BF_LAUNCH(2, 2, 0); break;
+#ifdef ORBM_DIAG
         case 4: BF_LAUNCH(4, 2, 1); break;   // diagnostic: no exact updates (results wrong)
+#endif
         case 5: BF_LAUNCH(4, 2, 2); break;   // diagnostic: exact update on every group
         case 6: BF_LAUNCH(4, 4, 0); break;
         case 8: BF_LAUNCH(BF_R, BF_U, 3); break;   // early abandon (opt-in)

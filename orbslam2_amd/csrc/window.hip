@@ -1195,7 +1195,10 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
 
 // tuning / test knob (not part of the public ABI): see g_win_variant
 extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
+#ifdef ORBM_DIAG
+// phase-timing diagnostics of collect_kernel (bits 1-3 switch phases off: wrong results); only in `make diag` builds
 extern "C" void orbm__window_cost_exact(int v) { g_win_cost_exact = v; }
+#endif
 
 extern "C" int orbm_search_proj_points_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset,
                                              float th, float ratio, const uint8_t *slot_flags, int32_t stride,

@@ -1,6 +1,7 @@
 """Sustained A/B of bf2nn kernel forms: far keyframe pairs (the config-5 triangle is 99.9 % such pairs), 16384 pairs per launch,
 each form timed over ~0.4 s of back-to-back launches, rounds interleaved.  ORBM_BF_FORMS=15,16,17 selects the forms."""
 import os, sys, time
+os.environ.setdefault("ORBM_DIAG_LIB", "1")   # the timing diagnostics live in `make -C orbslam2_amd/csrc diag` only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

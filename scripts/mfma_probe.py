@@ -1,6 +1,7 @@
 """Timing of the MFMA brute-force kernel alone (variant 9); ORBM_MFMA_DIAG=1 drops the selection epilogue, =2 stages the
 candidate tile only once (both give wrong results: attribution only)."""
 import sys, os
+os.environ.setdefault("ORBM_DIAG_LIB", "1")   # the timing diagnostics live in `make -C orbslam2_amd/csrc diag` only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

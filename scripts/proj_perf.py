@@ -1,6 +1,7 @@
 """Config 3 probe: SearchByProjection, N_INST independent (frame, 50k-query) instances per launch, distinct
 query sets (permutations of one base set) so that the queries really stream from HBM."""
 import sys, os, time
+os.environ.setdefault("ORBM_DIAG_LIB", "1")   # the timing diagnostics live in `make -C orbslam2_amd/csrc diag` only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -173,3 +173,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cc")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_ffi" not in src and "liborb_oracle" not in src and "orc_" not in src, f
+
+
+def test_release_library_exports_no_result_changing_knob():
+    """`nm -D liborbmatch_hip.so`: the only orbm__* knobs select between forms with identical results; the timing
+    diagnostics (phases of a kernel switched off) exist only in the `make diag` build."""
+    import subprocess
+    from orbslam2_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    knobs = {l.split()[-1] for l in out.splitlines() if " orbm__" in l}
+    assert knobs <= {"orbm__bf2nn_variant", "orbm__bow_variant", "orbm__bow_split_below", "orbm__bowm_wgs", "orbm__stereo_variant",
+                     "orbm__vocab_variant", "orbm__window_variant"}, knobs
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"ORBM_MFMA_DIAG" not in blob

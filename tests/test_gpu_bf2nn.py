@@ -272,3 +272,36 @@ def test_bf2nn_every_distance_value_is_exact(ctx, orc):
             wc, wm, wbd, wsd, _ = orc.bf2nn(frames[2 * d], frames[2 * d + 1], ratio, th)
             assert wc == counts[d] and wm[0] == match[d, 0] and wbd[0] == wb and wsd[0] == ws
     ctx.free_frames(ids)
+
+
+def test_stray_diagnostic_environment_cannot_change_results():
+    """The release library has no form that returns wrong matches: with the timing-diagnostic switches of the `make diag`
+    build set in the environment (ORBM_MFMA_DIAG) and a diagnostic variant requested through the knob, the LDS-staged MFMA
+    form still returns the oracle's matches.  Runs in a fresh process: the library reads its environment once."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from oracle import oracle_ffi as orc
+from orbslam2_amd import synth, _lib
+from orbslam2_amd.matcher import Context
+ctx = Context(0)
+L = _lib.load()
+kfs = synth.keyframe_pool(seed=77, n_kf=3, n=700, window=1100)
+ids = ctx.upload_frames(kfs)
+for variant in (0, 4, 18, 19, 20):
+    L.orbm__bf2nn_variant(variant)
+    counts, match, bd, sd = ctx.bf2nn([ids[0], ids[1]], [ids[1], ids[2]], 0.75, 50, stride=700, want_dist=False)
+    for k, (i, j) in enumerate(((0, 1), (1, 2))):
+        wc, wm, _, _, _ = orc.bf2nn(kfs[i], kfs[j], 0.75, 50)
+        assert counts[k] == wc and np.array_equal(match[k], wm), (variant, k)
+L.orbm__bf2nn_variant(0)
+assert not hasattr(L, "orbm__window_cost_exact")
+ctx.close()
+print("ok")
+'''
+    import os
+    env = dict(os.environ, ORBM_MFMA_DIAG="1", ORBMATCH_BF2NN_KERNEL="lds")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
