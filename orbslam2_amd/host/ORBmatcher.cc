@@ -46,6 +46,8 @@ struct ResKey {
 struct ResEntry {
     int32_t frame = -1;
     uint64_t print = 0;          // fingerprint of sampled descriptor rows and keypoints
+    uint64_t content = 0;        // hash of EVERY descriptor row and keypoint, taken at upload
+    uint64_t mp_version = ~0ull; // value of the caller's map-point version counter when `flags` was last refreshed
     size_t fv_size = 0;          // FeatureVector nodes the device copy was built from (0: none yet)
     vector<uint8_t> flags;       // mp_flags as last sent
     std::list<ResKey>::iterator lru;
@@ -62,6 +64,8 @@ ThreadCtx &Thread() {
     return t;
 }
 std::atomic<size_t> g_limit_kf{16384}, g_limit_frames{8};
+std::atomic<int> g_verify{1};                                    // 0 key only, 1 sampled fingerprint (default), 2 full content hash per call
+std::atomic<const std::atomic<uint64_t> *> g_mp_version{nullptr};
 }  // namespace
 orbm_ctx *NewCtx() {
     int dev = g_device;
@@ -161,6 +165,24 @@ uint64_t Fingerprint(const FrameLike &F) {
     return h;
 }
 
+// every descriptor row and every keypoint field the device copy holds (x, y, angle, octave), 8 bytes at a time
+template <class FrameLike>
+uint64_t ContentHash(const FrameLike &F) {
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)F.N, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    auto mix = [&h](int lane, uint64_t w) { h[lane] = (h[lane] ^ w) * 0x100000001B3ull; h[lane] ^= h[lane] >> 29; };
+    for (int i = 0; i < F.N; i++) {
+        uint64_t w[4];
+        memcpy(w, F.mDescriptors.template ptr<uint8_t>(i), 32);
+        for (int k = 0; k < 4; k++) mix(k, w[k]);
+        uint64_t a, b;
+        const float xy[2] = {F.mvKeysUn[i].pt.x, F.mvKeysUn[i].pt.y};
+        const float ao[2] = {F.mvKeysUn[i].angle, (float)F.mvKeysUn[i].octave};
+        memcpy(&a, xy, 8); memcpy(&b, ao, 8);
+        mix(i & 3, a); mix((i + 1) & 3, b);
+    }
+    return (h[0] * 31 + h[1]) ^ (h[2] * 131 + h[3]);
+}
+
 void DropResident(detail::ThreadCtx &t, std::map<detail::ResKey, detail::ResEntry>::iterator it) {
     orbm_frames_free(t.ctx, 1, &it->second.frame);
     t.lru[it->first.kf].erase(it->second.lru);
@@ -192,18 +214,25 @@ int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint 
     orbm_ctx *ctx = Ctx();
     detail::ThreadCtx &t = detail::Thread();
     const detail::ResKey key = KeyOf(kf, F);
-    const uint64_t fp = Fingerprint(F);
+    const int verify = detail::g_verify.load(std::memory_order_relaxed);
+    const uint64_t fp = verify >= 1 ? Fingerprint(F) : 0;
     auto it = t.resident.find(key);
-    if (it != t.resident.end() && (it->second.print != fp || (with_fv && it->second.fv_size != F.mFeatVec.size()))) {
+    if (it != t.resident.end() && ((verify >= 1 && it->second.print != fp) || (verify >= 2 && it->second.content != ContentHash(F)) ||
+                                   (with_fv && it->second.fv_size != F.mFeatVec.size()))) {
         DropResident(t, it);          // other content under the same key, or ComputeBoW ran after the upload
         it = t.resident.end();
     }
     if (it == t.resident.end()) {
         Flat f;
         Flatten(f, src, !F.mFeatVec.empty());
+        // the flags of the upload come from the CALLER's snapshot of the map points (the one it maps the results through),
+        // not from a second GetMapPointMatches(): LocalMapping may have changed the keyframe in between
+        for (int i = 0; i < F.N; i++) f.flags[i] = i < (int)mps.size() ? MpFlags(mps[i]) : 0;
+        const std::atomic<uint64_t> *vsrc = detail::g_mp_version.load(std::memory_order_acquire);
         detail::ResEntry e;
+        if (vsrc) e.mp_version = vsrc->load(std::memory_order_acquire);
         Check(orbm_frames_upload(ctx, 1, &f.v, &e.frame), "orbm_frames_upload");
-        e.print = fp; e.fv_size = F.mFeatVec.size(); e.flags.swap(f.flags);
+        e.print = verify >= 1 ? fp : Fingerprint(F); e.content = ContentHash(F); e.fv_size = F.mFeatVec.size(); e.flags.swap(f.flags);
         t.lru[kf].push_front(key);
         e.lru = t.lru[kf].begin();
         it = t.resident.emplace(key, std::move(e)).first;
@@ -213,6 +242,15 @@ int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint 
     }
     detail::ResEntry &e = it->second;
     t.lru[kf].splice(t.lru[kf].begin(), t.lru[kf], e.lru);
+    // extension hook (SetMapPointVersion): the host project counts every change of a map point's bad flag / observations and of
+    // a frame's or keyframe's map-point vector; while the counter stands where it stood at the last refresh the flags on the
+    // device are current and the O(N) sweep below (a mutex-guarded isBad() + Observations() per keypoint) is skipped
+    const std::atomic<uint64_t> *vsrc = detail::g_mp_version.load(std::memory_order_acquire);
+    uint64_t vnow = 0;
+    if (vsrc) {
+        vnow = vsrc->load(std::memory_order_acquire);
+        if (vnow == e.mp_version) return e.frame;
+    }
     bool same = true;
     const int n = F.N;
     for (int i = 0; i < n; i++) {
@@ -220,6 +258,7 @@ int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint 
         if (fl != e.flags[i]) { e.flags[i] = fl; same = false; }
     }
     if (!same && n > 0) Check(orbm_frame_set_mp_flags(ctx, e.frame, e.flags.data()), "orbm_frame_set_mp_flags");
+    if (vsrc) e.mp_version = vnow;      // read BEFORE the sweep: a change during it bumps the counter past this value
     return e.frame;
 }
 
@@ -291,6 +330,8 @@ void DecomposeSim3(const cv::Mat &Scw, float *Rcw, float *tcw, float *Ow) {
 
 void ORBmatcher::SetDevice(int device) { g_device = device; }
 void ORBmatcher::SetResidentLimits(size_t nKeyFrames, size_t nFrames) { detail::g_limit_kf = nKeyFrames; detail::g_limit_frames = nFrames; }
+void ORBmatcher::SetResidencyVerify(int level) { detail::g_verify = level < 0 ? 0 : level > 2 ? 2 : level; }
+void ORBmatcher::SetMapPointVersion(const std::atomic<uint64_t> *counter) { detail::g_mp_version.store(counter, std::memory_order_release); }
 void ORBmatcher::Prefetch(KeyFrame *pKF) { if (pKF && pKF->N > 0) Resident(pKF, true); }
 void ORBmatcher::Evict(KeyFrame *pKF) {
     detail::ThreadCtx &t = detail::Thread();

@@ -15,6 +15,8 @@
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <atomic>
+#include <cstdint>
 #include <set>
 #include <utility>
 #include <vector>
@@ -89,6 +91,16 @@ public:
     static void Evict(KeyFrame *pKF);
     static void Evict(const Frame &F);
     static void SetResidentLimits(size_t nKeyFrames, size_t nFrames);
+    // How a resident copy is checked against the host object on every call.  0: by key only (mnId, descriptor buffer, N);
+    // 1 (default): + a fingerprint of three sampled rows / keypoints; 2: + a hash of EVERY descriptor row and keypoint
+    // (taken at upload, recomputed per call: ~6 us per 2000-keypoint frame) -- for host projects that rewrite
+    // mDescriptors / mvKeysUn in place, which ORB-SLAM2 itself never does (Frame.h:235-253 are written by the constructor).
+    static void SetResidencyVerify(int level);
+    // Optional: a counter the host project bumps whenever a MapPoint's bad flag or observation count, or any Frame's /
+    // KeyFrame's map-point vector, changes.  While it stands still the per-call sweep over the N map points of a resident
+    // frame (isBad() + Observations(), both mutex-guarded: MapPoint.cc:212,315) is skipped.  nullptr (default): the
+    // reference-exact sweep on every call.
+    static void SetMapPointVersion(const std::atomic<uint64_t> *counter);
 
     // The candidate loops around SearchByBoW as ONE launch: Tracking::Relocalization (Tracking.cc:1778-1801,
     // `matcher.SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i])` for every candidate) and

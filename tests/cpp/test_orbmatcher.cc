@@ -296,6 +296,49 @@ static void TestResidency() {
         EXPECT(cnt2 == want2 && bad == 0, "refilled object: count %d vs %d, %d mismatches", cnt2, want2, bad);
         ORBmatcher::Evict(G);
     }
+    // in-place change of ONE descriptor row that the sampled fingerprint does not look at: found with SetResidencyVerify(2)
+    {
+        Raw rm = MakeRaw(600, lm, 200, 1200, 12, 0.3, 0.0, 0, 0);
+        Frame H; FillFrame(H, rm);
+        vector<MapPoint *> got;
+        const int orig = matcher.SearchByBoW(&A, H, got);              // uploads H
+        // every row except the three the sampled fingerprint looks at (0, N/2, N-1) gets a fresh random descriptor
+        for (int row = 1; row < rm.n - 1; row++) {
+            if (row == rm.n / 2) continue;
+            const Desc d = RandDesc();
+            memcpy(H.mDescriptors.ptr<uint8_t>(row), d.b, 32);
+            memcpy(rm.desc[row].b, d.b, 32);
+        }
+        orbm_frame_view va = ra.view(true), vm = rm.view(false);
+        vector<int32_t> m(rm.n); uint64_t nc;
+        const int want = orc_search_bow(0, &va, &vm, 0.75f, 1, m.data(), &nc);
+        ORBmatcher::SetResidencyVerify(2);
+        const int cnt = matcher.SearchByBoW(&A, H, got);
+        int bad = 0;
+        for (int i = 0; i < H.N; i++) bad += got[i] != (m[i] >= 0 ? A.mvpMapPoints[m[i]] : nullptr);
+        EXPECT(cnt == want && bad == 0 && want != orig, "in-place row change with full verification: count %d vs %d (before the change %d), %d mismatches", cnt, want, orig, bad);
+        ORBmatcher::SetResidencyVerify(1);
+        ORBmatcher::Evict(H);
+    }
+    // the map-point version hook: while the counter stands still the flag sweep is skipped, a bump brings the flags up to date
+    {
+        std::atomic<uint64_t> version{1};
+        ORBmatcher::SetMapPointVersion(&version);
+        const int before = check("version hook, first call");
+        vector<MapPoint *> got0, got1;
+        matcher.SearchByBoW(&A, &B, got0);
+        for (int i = 0; i < ra.n; i++)
+            if (i % 3 == 0 && A.mvpMapPoints[i] && !A.mvpMapPoints[i]->mbBad) { A.mvpMapPoints[i]->mbBad = true; ra.flags[i] |= ORBM_MP_BAD; }
+        const int stale = matcher.SearchByBoW(&A, &B, got1);           // counter not bumped: the device still holds the old flags
+        EXPECT(stale == before || got1.size() == got0.size(), "version hook: unexpected result size");
+        int same = 0;
+        for (size_t i = 0; i < got0.size(); i++) same += got0[i] == got1[i];
+        EXPECT(same == (int)got0.size(), "version hook: the sweep ran although the counter did not move (%d of %zu equal)", same, got0.size());
+        version++;
+        const int fresh = check("version hook, after the bump");
+        EXPECT(fresh != before, "version hook: the bump should change the result (%d both times)", fresh);
+        ORBmatcher::SetMapPointVersion(nullptr);
+    }
     // the candidate loops in one launch (Tracking.cc:1778-1801, LoopClosing.cc:433-477) = the per-candidate calls
     {
         const int K = 12;
