@@ -269,7 +269,10 @@ int orbm_pack_records(orbm_ctx *ctx, int n_pairs, const uint32_t *pair_id, const
                       uint32_t *totals, int io_on_device);
 /* Match + compact in one call; the match rows stay in a workspace of the context.  kind 0 = brute-force 2-NN
  * (ratio, th as orbm_bf2nn_batch), 1 = SearchByBoW(KF,KF), 2 = SearchByBoW(KF,F) (ratio, check_ori as orbm_search_bow_batch).
- * stride >= the rows a pair needs (n of the a-frame; of the b-frame for kind 2), at most 65536. */
+ * stride >= the rows a pair needs (n of the a-frame; of the b-frame for kind 2), at most 65536.  The VALUE half of a
+ * list entry indexes the pair's other frame (the b-frame; the a-frame for kind 2), which must have at most 65536
+ * keypoints as well: checked (ORBM_ELIMIT) when the pair lists are host memory; with io_on_device the ids cannot be read
+ * here and the limit is the caller's contract. */
 int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                         const uint32_t *pair_id, float ratio, int th, int check_ori, int32_t stride, int threshold,
                         orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap, uint32_t *totals, int io_on_device);

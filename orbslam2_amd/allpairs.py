@@ -125,35 +125,44 @@ class RecordExchange:
         self.torch, self.dist, self.rank, self.world, self.P = torch, dist, rank, world, batch
         self.dev, self.sink = comm_device, sink
         self.bufs = self.recv = None
+        self.list_cap = list_cap
+        self.overflows = 0           # batches whose lists did not fit list_cap (cut there; every rank keeps exchanging)
         if world > 1 and rank == 0:
             self.bufs = [torch.empty(batch + 1, dtype=torch.int64, device=comm_device) for _ in range(world)]
             self.recv = [torch.empty(list_cap if r else 0, dtype=torch.int32, device=comm_device) for r in range(world)]
 
     def submit(self, summ, lists, n_entries: int):
         torch, dist = self.torch, self.dist
+        # No rank ever raises between the collectives of a batch (the others would wait in gather / irecv forever): a batch
+        # whose lists exceed list_cap is CUT at list_cap on both sides -- sender and receiver compute the same length from the
+        # header, which carries the true count -- and counted in `overflows`; all_pairs reports it after the last exchange.
+        if n_entries > self.list_cap:
+            self.overflows += 1
+        n_send = min(n_entries, self.list_cap, int(lists.numel()))
         if self.world == 1:
             if self.sink:
-                self.sink(0, summ[: self.P], lists[:n_entries])
+                self.sink(0, summ[: self.P], lists[:n_send])
             return
         dist.gather(summ, self.bufs, dst=0)
         if self.rank != 0:
-            if n_entries:
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, lists[:n_entries], 0)]):
+            if n_send:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, lists[:n_send], 0)]):
                     w.wait()
             return
         hdr = torch.stack([b[self.P] for b in self.bufs]).cpu().numpy()          # one small read: every rank's header
         entries = [int(h >> 32) for h in hdr]
         ops = []
         for r in range(1, self.world):
-            if entries[r] > self.recv[r].numel():
-                raise RuntimeError(f"rank {r} sends {entries[r]} list entries, receive buffer holds {self.recv[r].numel()}")
+            if entries[r] > self.list_cap:
+                self.overflows += 1
+                entries[r] = self.list_cap
             if entries[r]:
                 ops.append(dist.P2POp(dist.irecv, self.recv[r][: entries[r]], r))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         if self.sink:
-            self.sink(0, summ[: self.P], lists[:n_entries])
+            self.sink(0, summ[: self.P], lists[:n_send])
             for r in range(1, self.world):
                 self.sink(r, self.bufs[r][: self.P], self.recv[r][: entries[r]])
 
@@ -187,6 +196,15 @@ def all_pairs(torch, dist, n_kf: int, batch: int, threshold: int, batch_fn: Call
             pid = np.concatenate([pid, np.full(pad, PAD_ID, np.uint32)])
         summ, lists, n_entries = batch_fn(a, b, pid)
         ex.submit(summ, lists, n_entries)
+    # every exchange is done: now (and only now) an overflow may become an error, the same one on every rank
+    over = ex.overflows
+    if world > 1:
+        t = torch.tensor([over], dtype=torch.int64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        over = int(t.item())
+    if over:
+        raise RuntimeError(f"{over} batch(es) produced more list entries than list_cap = {ex.list_cap}: their lists were cut "
+                           f"(summaries are complete); run again with a larger list_cap")
     return res
 
 
@@ -210,11 +228,10 @@ def device_batch_fn(torch, ctx, frame_ids, kind: int, ratio: float, th: int, che
         ctx.allpairs_batch_dev(kind, P, fa.data_ptr(), fb.data_ptr(), tp.data_ptr(), ratio, th, check_ori, stride, threshold,
                                summ.data_ptr(), lists.data_ptr(), list_cap, summ.data_ptr() + 8 * P)
         torch.cuda.current_stream().synchronize()
-        n_entries = int(summ[P].item() >> 32)
-        if n_entries > list_cap:
-            raise RuntimeError(f"{n_entries} list entries in one batch, buffer holds {list_cap}")
+        n_entries = int(summ[P].item() >> 32)       # may exceed list_cap: RecordExchange cuts the lists and reports it at the end
+        keep = min(n_entries, list_cap)
         if str(comm_device) == "cpu":
-            return summ.cpu(), lists[:n_entries].cpu(), n_entries
-        return summ.clone(), lists[:n_entries].clone(), n_entries
+            return summ.cpu(), lists[:keep].cpu(), n_entries
+        return summ.clone(), lists[:keep].clone(), n_entries
 
     return fn

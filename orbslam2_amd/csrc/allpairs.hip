@@ -161,6 +161,10 @@ int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *fra
         for (int p = 0; p < n_pairs; p++) {
             const int need = kind == 2 ? ctx->h_frames[frame_b[p]].n : ctx->h_frames[frame_a[p]].n;
             if (need > stride) return orbm_fail(ctx, ORBM_EINVAL, "allpairs_batch: stride %d < %d rows needed by pair %d", stride, need, p);
+            // a list entry is (row | value << 16): the value indexes the OTHER frame of the pair, which the stride does not bound
+            const int other = kind == 2 ? ctx->h_frames[frame_a[p]].n : ctx->h_frames[frame_b[p]].n;
+            if (other > 65536)
+                return orbm_fail(ctx, ORBM_ELIMIT, "allpairs_batch: pair %d matches into a frame of %d keypoints: value indices must fit 16 bits", p, other);
         }
     }
     if (kind == 0 && (rc = orbm_bf2nn_prepare(ctx))) return rc;

@@ -811,6 +811,8 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
         max_n8 = std::max(max_n8, n8);
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // everything that can fail without touching the host mirror first: the id list's workspace, then the arena
+    { int rc = orbm_ws_reserve(ctx, need.size() * 4); if (rc) return rc; }
     Arena ar;
     { int rc = orbm_arena_alloc(ctx, total, &ar); if (rc) return rc; }
     ar.live = (int)need.size();
@@ -824,29 +826,44 @@ int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids) {
         slot_arena[id] = arena_id;
         lo = std::min(lo, (size_t)id); hi = std::max(hi, (size_t)id);
     }
-    int rc = orbm_ws_reserve(ctx, need.size() * 4);
-    if (rc) return rc;
-    const size_t tab_bytes = (hi - lo + 1) * sizeof(FrameDev), id_bytes = need.size() * 4, o_ids = align_up(tab_bytes, 256);
-    if (char *pin = (char *)orbm_pin_up(ctx, o_ids + id_bytes)) {
-        memcpy(pin, ctx->h_frames.data() + lo, tab_bytes);
-        memcpy(pin + o_ids, need.data(), id_bytes);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames + lo, pin, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->ws, pin + o_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, tab_bytes, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(ctx->ws, need.data(), id_bytes, hipMemcpyHostToDevice));
+    // From here on the host mirror says "these frames have an image".  If a copy, the launch or the synchronisation fails the
+    // images were not (or not provably) built: take the pointers back, on the host and -- best effort -- in the device table,
+    // and release the arena, so that the next call builds them again instead of multiplying uninitialised rows.
+    auto build = [&]() -> int {
+        const size_t tab_bytes = (hi - lo + 1) * sizeof(FrameDev), id_bytes = need.size() * 4, o_ids = align_up(tab_bytes, 256);
+        if (char *pin = (char *)orbm_pin_up(ctx, o_ids + id_bytes)) {
+            memcpy(pin, ctx->h_frames.data() + lo, tab_bytes);
+            memcpy(pin + o_ids, need.data(), id_bytes);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_frames + lo, pin, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->ws, pin + o_ids, id_bytes, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            HIPCHK(ctx, hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, tab_bytes, hipMemcpyHostToDevice));
+            HIPCHK(ctx, hipMemcpy(ctx->ws, need.data(), id_bytes, hipMemcpyHostToDevice));
+        }
+        if (bits == 5) {
+            const int bpf = (max_n8 + 127) / 128;
+            hipLaunchKernelGGL(expand_image_fv_kernel, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+        } else if (bits == 8) {
+            const int bpf = max_n8 / 16;
+            hipLaunchKernelGGL(expand_image_kernel<8>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+        } else {
+            const int bpf = max_n8 / 32;
+            hipLaunchKernelGGL(expand_image_kernel<4>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // the pinned block and the id list in ws are reused by the caller
+        return ORBM_OK;
+    };
+    const int rc = build();
+    if (rc) {
+        const std::string why = ctx->err;                  // the message of the step that failed, not of the clean-up
+        for (int32_t id : need) { image_of(ctx->h_frames[id]) = nullptr; slot_arena[id] = -1; }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(ctx->d_frames + lo, ctx->h_frames.data() + lo, (hi - lo + 1) * sizeof(FrameDev), hipMemcpyHostToDevice);
+        ctx->arenas[arena_id].live = 0;
+        orbm_arena_release(ctx, ctx->arenas[arena_id]);
+        ctx->err = why;
+        return rc;
     }
-    if (bits == 5) {
-        const int bpf = (max_n8 + 127) / 128;
-        hipLaunchKernelGGL(expand_image_fv_kernel, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
-    } else if (bits == 8) {
-        const int bpf = max_n8 / 16;
-        hipLaunchKernelGGL(expand_image_kernel<8>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
-    } else {
-        const int bpf = max_n8 / 32;
-        hipLaunchKernelGGL(expand_image_kernel<4>, dim3((unsigned)(need.size() * bpf)), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)ctx->ws, bpf);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));        // the pinned block and the id list in ws are reused by the caller
     return ORBM_OK;
 }

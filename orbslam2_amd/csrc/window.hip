@@ -1086,40 +1086,52 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     {
         const int waves_per_inst = (max_q + 63) / 64;
         if (waves_per_inst == 0) return launch_claims<MODE, false, false>(ctx, P, n_inst, max_n, 256, 0, nullptr, nullptr);
-        const size_t rows = (size_t)n_inst * waves_per_inst;
         // per query: 16 bytes of head (always written) + room for tcap tail words (written for queries with more than 4
-        // candidates): 60 unless the batch is so large that this would not fit 8 GB (queries with more candidates than that
-        // are still exact: the claims kernel walks their window again)
+        // candidates).  The scratch (ws2, grow-only for the context's lifetime) is capped at WIN_SCRATCH_CAP: first the tail
+        // shrinks (60 -> 28 words; queries with more candidates than that are still exact, the claims kernel walks their window
+        // again), then the batch is cut into runs of instances that go through the two kernels one after the other.
+        constexpr size_t WIN_SCRATCH_CAP = (size_t)1 << 30;
+        const size_t q_inst = (size_t)waves_per_inst * 64;
         int tcap = 60;
-        while (tcap > 12 && rows * 64 * (16 + 4 * (size_t)tcap) > ((size_t)8 << 30)) tcap = tcap / 2 & ~3;
-        int rc = orbm_ws2_reserve(ctx, rows * 64 * (16 + 4 * (size_t)tcap) + 256);
+        while (tcap > 28 && (size_t)n_inst * q_inst * (16 + 4 * (size_t)tcap) > WIN_SCRATCH_CAP) tcap -= 16;
+        const size_t inst_bytes = q_inst * (16 + 4 * (size_t)tcap);
+        const int run_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_inst, WIN_SCRATCH_CAP / inst_bytes));
+        int rc = orbm_ws2_reserve(ctx, (size_t)run_max * inst_bytes + 256);
         if (rc) return rc;
-        v4u *head = (v4u *)ctx->ws2;
-        uint32_t *tail = (uint32_t *)(head + rows * 64);
         // enough workgroups to fill the chip, each with enough rows to pay for building the index
         constexpr int WAVES = COLLECT_THREADS / 64;
         // one workgroup per CU is enough (the LDS index allows no second one) and every workgroup builds the index once
         static const int wg_target_env = [] { const char *e = getenv("ORBM_WIN_WGS"); return e ? atoi(e) : 0; }();
         const int wg_target = wg_target_env > 0 ? wg_target_env : std::max(64, ctx->prop.multiProcessorCount);
-        int wgs_per_inst = std::max(1, std::min((wg_target + n_inst - 1) / n_inst, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
-        // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
-        const int groups = (long long)n_inst * wgs_per_inst < wg_target ? 1 : 2;
-        if (groups == 1) wgs_per_inst = std::max(1, std::min((wg_target + n_inst - 1) / n_inst, (waves_per_inst + WAVES - 1) / WAVES));
-        // still fewer workgroups than CUs (one large instance): narrower rows, so that the instance spreads over the chip
-        int qt = COLLECT_THREADS;
-        if (groups == 1 && (long long)n_inst * wgs_per_inst < wg_target) {
-            const long long per_wg = ((long long)waves_per_inst * 64 * n_inst + wg_target - 1) / wg_target;
-            qt = (int)std::min<long long>(COLLECT_THREADS, std::max<long long>(64, (per_wg + 63) / 64 * 64));
-            wgs_per_inst = std::max(1, (waves_per_inst * 64 + qt - 1) / qt);
-        }
         const bool desc_lds = collect_lds_bytes(cfg, true) <= 160 * 1024 && !(g_win_cost_exact & 32);
         const size_t lds = collect_lds_bytes(cfg, desc_lds);
         HIPCHK(ctx, (orbm_allow_dynamic_lds<&collect_kernel<MODE>>(ctx, lds)));
-        hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(n_inst * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, P,
-                           waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact, desc_lds ? 1 : 0);
-        HIPCHK(ctx, hipGetLastError());
         const int threads = max_q >= 1024 ? 1024 : (max_q > 256 ? 512 : 256);
-        return launch_claims<MODE, false, true>(ctx, P, n_inst, max_n, threads, waves_per_inst, head, tail, tcap);
+        for (int i0 = 0; i0 < n_inst; i0 += run_max) {
+            const int ni = std::min(run_max, n_inst - i0);
+            WinParams R = P;                                   // this run's instances: every per-instance array moved up by i0
+            R.frame_ids += i0; R.qset_ids += i0; R.out += (size_t)i0 * P.stride; R.counts += i0;
+            if (R.slot_flags) R.slot_flags += (size_t)i0 * P.stride;
+            v4u *head = (v4u *)ctx->ws2;
+            uint32_t *tail = (uint32_t *)(head + (size_t)ni * q_inst);
+            int wgs_per_inst = std::max(1, std::min((wg_target + ni - 1) / ni, (waves_per_inst + 2 * WAVES - 1) / (2 * WAVES)));
+            // few instances: one row of 64 queries per wave instead of two, so that an instance spreads over twice the workgroups
+            const int groups = (long long)ni * wgs_per_inst < wg_target ? 1 : 2;
+            if (groups == 1) wgs_per_inst = std::max(1, std::min((wg_target + ni - 1) / ni, (waves_per_inst + WAVES - 1) / WAVES));
+            // still fewer workgroups than CUs (one large instance): narrower rows, so that the instance spreads over the chip
+            int qt = COLLECT_THREADS;
+            if (groups == 1 && (long long)ni * wgs_per_inst < wg_target) {
+                const long long per_wg = ((long long)waves_per_inst * 64 * ni + wg_target - 1) / wg_target;
+                qt = (int)std::min<long long>(COLLECT_THREADS, std::max<long long>(64, (per_wg + 63) / 64 * 64));
+                wgs_per_inst = std::max(1, (waves_per_inst * 64 + qt - 1) / qt);
+            }
+            hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(ni * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, R,
+                               waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact, desc_lds ? 1 : 0);
+            HIPCHK(ctx, hipGetLastError());
+            rc = launch_claims<MODE, false, true>(ctx, R, ni, max_n, threads, waves_per_inst, head, tail, tcap);
+            if (rc) return rc;
+        }
+        return ORBM_OK;
     }
     return ORBM_OK;
 }

@@ -186,3 +186,31 @@ def test_release_library_exports_no_result_changing_knob():
                      "orbm__vocab_variant", "orbm__window_variant"}, knobs
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"ORBM_MFMA_DIAG" not in blob
+
+
+def _overflow_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        allpairs.all_pairs(torch, dist, 45, batch=64, threshold=20, batch_fn=_fake_batch_fn(20), rank=rank, world=world, tile=8, list_cap=8)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, "raised" if "list_cap" in str(e) else repr(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_list_overflow_is_an_error_on_every_rank_not_a_hang():
+    """A batch whose lists exceed list_cap must not stop one rank between two collectives: every rank finishes the
+    exchange (lists cut at list_cap) and then raises the same error."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got == {0: "raised", 1: "raised"}, got
