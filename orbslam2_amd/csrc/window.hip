@@ -25,6 +25,7 @@
 // the best / second-best pair of a final query is the one the sequential loop would have found; the lowest
 // unresolved query is always final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -502,13 +503,740 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     }
 }
 
+// ---- fused form: ONE launch, one 1024-thread workgroup per (frame, query set) instance, queries taken in index order
+// FUSED_CHUNK at a time.  Waves 1..15 search (one query per lane), wave 0 settles the claims of the chunk before while
+// they do.  What makes this the fast form for the searches that write slot state (a6, a11, a5) is what the reference's own
+// loop does first: it tests the slot (`if(F.mvpMapPoints[idx]) if(...Observations()>0) continue;`, ORBmatcher.cc:113-115,
+// :1879-1881, :2048, :512) BEFORE it looks at the descriptor.  Slots only ever become blocked, and the state a searching
+// wave reads holds claims of LOWER-index queries only (claims of chunk c are applied while chunk c + 1 is searched, claims
+// of chunk c + 1 start after its search has ended), so a record that reads "blocked" is blocked for this query in the
+// sequential order too and is dropped before the float gates, the descriptor gather and the distance; one that reads
+// "free" is looked at again by the rounds.  Once the frame's slots have filled up -- 50 000 map points into 2000
+// keypoints: after the first few thousand queries -- a query costs its walk over the index and nothing else: no
+// descriptor load (its own 32 bytes are requested only when a free record passes the gates), no distance, no record
+// anywhere.  A query with a free candidate within the threshold is LIVE: its four smallest candidate words, sorted, go to
+// a pending list in LDS (further words to a per-thread tail in global scratch, rarely), and wave 0 runs the same
+// evaluate / contested / decide rounds as window_kernel on up to 64 live queries at a time, one per lane, in index order,
+// wave-synchronously: no workgroup barrier inside the rounds, and a post is (round stamp << 6 | 63 - lane) under
+// atomicMax, so the post array never needs clearing.  Two workgroup barriers per chunk hand the pending list over.
+constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_CHUNK = FUSED_THREADS - 64;   // queries per chunk: waves 1..15
+constexpr int PEND_WORDS = 10;                    // pending entry: meta, the query's angle, eight candidate words
+constexpr int FPARK = 2;                          // survivors a lane parks (in registers) between two distance passes
+
+static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask) {
+    const int total = c.base[c.nstruct];
+    const size_t offn = (size_t)((total + 6) & ~1);
+    const size_t n4 = (size_t)((c.n_cap + 3) & ~3);
+    return (((offn / 2 + 3) & ~(size_t)3)) * 4 + n4 * 16 + (size_t)((c.rec_cap + 7) & ~7) * 2 + (size_t)((c.n_cap + 7) & ~7) * 2 +
+           n4 * 4 * (3 + (with_binmask ? 1 : 0)) + (size_t)64 * PEND_WORDS * 4 + n4 * 4 /* l_pos */ +
+           (size_t)(((c.rec_cap + 31) / 32 + 4) & ~3) * 4 /* fbits */ + (8 * 12 + 8 * 96) * 4 /* fblk, fcnt */ + 64;
+}
+
+// raw per-query parameters as loaded (requested a chunk ahead), decoded when the chunk is searched
+struct RawQ {
+    v4u pk;                      // MODE_PROJ
+    float f0, f1, f2, f3, ang;   // other modes: u, v, radius, ur, angle | MODE_INIT: prev x, prev y, -, -, angle
+    int l0, l1;
+    uint32_t flags;              // MODE_INIT: octave
+    bool in_range;
+};
+
+template <int MODE>
+__device__ __forceinline__ RawQ raw_load(const WinParams &P, const QSrc &S, int qi) {
+    RawQ r;
+    r.pk = v4u{0, 0, 0, 0}; r.f0 = r.f1 = r.f2 = r.f3 = r.ang = 0.f; r.l0 = r.l1 = -1; r.flags = 0;
+    r.in_range = qi < S.Q;
+    if (!r.in_range) return r;
+    if (MODE == MODE_INIT) {
+        r.flags = S.F1.octave[qi];
+        r.f0 = P.prev_xy[2 * qi]; r.f1 = P.prev_xy[2 * qi + 1];
+        r.ang = S.F1.angle[qi];
+    } else if (MODE == MODE_PROJ) {
+        r.pk = ((gptr<const v4u>)S.QS.pk)[qi];
+    } else {
+        const QSetG &QS = S.QS;
+        r.flags = QS.flags[qi];
+        r.f0 = QS.f0[qi]; r.f1 = QS.f1[qi]; r.f2 = QS.f2[qi]; r.l0 = QS.l0[qi]; r.l1 = QS.l1[qi];
+        if (QS.f3) r.f3 = QS.f3[qi];
+        if (QS.angle) r.ang = QS.angle[qi];
+    }
+    return r;
+}
+
+// = load_params() on the loaded values; sf = the frame's scale factors (in LDS)
+template <int MODE>
+__device__ __forceinline__ Query raw_decode(const WinParams &P, const RawQ &r, const float *sf) {
+    Query q;
+    q.d0 = q.d1 = v4u{0, 0, 0, 0};
+    q.x = q.y = q.r = q.xr = q.angle = 0.f; q.minL = q.maxL = -1; q.ql = 0; q.flags = 0; q.valid = false;
+    if (!r.in_range) return q;
+    if (MODE == MODE_INIT) {
+        if (r.flags == 0) {                                                           // :582-584
+            q.valid = true;
+            q.x = r.f0; q.y = r.f1;
+            q.r = (float)P.window; q.minL = 0; q.maxL = 0;                            // :587
+            q.angle = r.ang;
+        }
+    } else if (MODE == MODE_PROJ) {
+        const v4u k = r.pk;
+        q.flags = (k.w >> 8) & 0xFFu;
+        if (q.flags & ORBM_Q_VALID) {
+            q.valid = true;
+            q.x = __uint_as_float(k.x); q.y = __uint_as_float(k.y); q.xr = __uint_as_float(k.z);
+            const int lvl = (int)(k.w & 0xFFu);
+            float rv = ((k.w >> 16) & 1u) ? 2.5f : 4.0f;
+            if (P.th != 1.0f) rv = __fmul_rn(rv, P.th);                              // :61, :84-85
+            q.r = __fmul_rn(rv, sf[lvl & (ORBM_MAX_LEVELS - 1)]);                     // :89
+            q.minL = lvl - 1; q.maxL = lvl;
+        }
+    } else {
+        q.flags = r.flags;
+        if (q.flags & ORBM_Q_VALID) {
+            q.valid = true;
+            q.x = r.f0; q.y = r.f1; q.r = r.f2; q.minL = r.l0; q.maxL = r.l1; q.xr = r.f3; q.angle = r.ang;
+        }
+    }
+    return q;
+}
+
+// workgroup barrier that orders LDS accesses only: the parameter loads a wave has requested for the NEXT chunk stay in flight
+// across it (__syncthreads() would wait for them: its fence covers global memory too)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, CoarseCfg cfg, uint32_t *tail_scratch, int tcap, int32_t *redo_flags, unsigned long long *trace) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ int s_k[8], s_base[9];
+    __shared__ uint32_t s_part[FUSED_THREADS / 64];
+    __shared__ unsigned long long s_live[16];
+    __shared__ int s_hist[36];                                                    // hist[32], nmatch, keep[3]
+    __shared__ float s_sf[ORBM_MAX_LEVELS];
+    __shared__ int s_any[3];
+    __shared__ uint32_t s_stamp_mem;
+    __shared__ int s_free_total;                                                  // free (not blocked) slots of the frame
+    uint32_t *s_stamp = &s_stamp_mem;
+    constexpr int NARROW_MAX = 64;                                                // up to this many live queries of a chunk go to wave 0
+    constexpr bool HIST_MODE = MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT;
+    constexpr bool USES_SECOND = MODE == MODE_PROJ || MODE == MODE_INIT;
+    constexpr int NW = 8;                                                         // candidate words in a pending entry
+    const int inst = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameG F(P.frames[P.frame_ids[inst]]);
+    const int n = F.n;
+    gptr<int32_t> redo_flag = in_global(redo_flags) + inst;
+    if (tid == 0) *redo_flag = 0;
+    const int total = cfg.base[cfg.nstruct];
+    const int offn = (total + 6) & ~1;
+    const int n4 = (cfg.n_cap + 3) & ~3;
+    const int fwords = ((cfg.rec_cap + 31) / 32 + 4) & ~3;
+    uint16_t *c_off = reinterpret_cast<uint16_t *>(lds);
+    v4f *c_rec = reinterpret_cast<v4f *>(lds + ((offn / 2 + 3) & ~3));
+    uint16_t *c_lst = reinterpret_cast<uint16_t *>(c_rec + n4);
+    uint16_t *l_kp = c_lst + ((cfg.rec_cap + 7) & ~7);                            // stream position -> keypoint
+    uint32_t *state = reinterpret_cast<uint32_t *>(l_kp + ((cfg.n_cap + 7) & ~7));   // ORBM_MP_* flags | vMatchedDistance, by stream position
+    int32_t *owner = (int32_t *)(state + n4);
+    uint32_t *post = state + 2 * (size_t)n4;
+    uint32_t *binmask = state + 3 * (size_t)n4;                                   // HIST_MODE only
+    uint32_t *pending = state + (3 + (HIST_MODE ? 1 : 0)) * (size_t)n4;
+    uint16_t *l_pos = reinterpret_cast<uint16_t *>(pending + (size_t)64 * PEND_WORDS);   // [2][n4]: where stream position j sits in c_lst (0xFFFF: nowhere)
+    uint32_t *fbits = reinterpret_cast<uint32_t *>(l_pos + 2 * (size_t)n4);       // bit p: the record at c_lst[p] is free (not blocked)
+    // fblk[s * 12 + BY] bit BX: structure s holds a free record in the block of 4 x 4 grid cells (BX, BY); fcnt = how many
+    // (two 16-bit counters per word).  A query whose window touches no such block is finished without a walk.
+    uint32_t *fblk = fbits + fwords;
+    uint32_t *fcnt = fblk + 8 * 12;
+    int *hist = s_hist, *nmatch = s_hist + 32, *keep = s_hist + 33;
+#ifdef ORBM_DIAG
+    if (trace && inst == 0 && tid == 0) trace[0] = wall_clock64();
+#endif
+    if (tid < 8) s_k[tid] = cfg.kshift[tid];
+    if (tid < 9) s_base[tid] = cfg.base[tid];
+    if (tid < ORBM_MAX_LEVELS) s_sf[tid] = F.sf[tid];
+    // ---- the index (as collect_kernel: buckets of stream positions per octave pair, coarse column and fine row)
+    uint32_t *cnt32 = lds;
+    for (int i = tid; i < offn / 2; i += FUSED_THREADS) cnt32[i] = 0;
+    for (int i = tid; i < fwords + 8 * 12 + 8 * 96; i += FUSED_THREADS) fbits[i] = 0;
+    __syncthreads();
+    const int T = (int)F.cell_off[ORBM_GRID_CELLS];
+    const bool pairs = cfg.nstruct > 1;
+    auto bucket_add = [&](int b) {
+        const uint32_t old = atomicAdd(&cnt32[(b + 2) >> 1], ((b + 2) & 1) ? 0x10000u : 1u);
+        return ((b + 2) & 1) ? old >> 16 : old & 0xFFFFu;
+    };
+    for (int j = tid; j < T; j += FUSED_THREADS) {
+        const uint32_t w = __float_as_uint(F.cell_rec[j].w);
+        const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
+        if (pairs) {
+            if (oct <= 7) bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy);
+            if (oct + 1 <= 7) bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy);
+        } else {
+            bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy);
+        }
+    }
+    __syncthreads();
+    {
+        const int per = (total + FUSED_THREADS - 1) / FUSED_THREADS;
+        const int i0 = min(total, tid * per), i1 = min(total, i0 + per);
+        uint32_t sum = 0;
+        for (int i = i0; i < i1; i++) sum += c_off[i + 2];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w2 = 0; w2 < wave; w2++) run += s_part[w2];
+        for (int i = i0; i < i1; i++) { const uint32_t c = c_off[i + 2]; c_off[i + 2] = (uint16_t)run; run += c; }
+        if (tid == 0) { c_off[0] = 0; c_off[1] = 0; }
+    }
+    __syncthreads();
+    const QSrc S = query_source<MODE>(P, inst);
+    const int Q = S.Q;
+    int32_t *out = P.out + (size_t)inst * P.stride;
+    auto is_blocked = [&](uint32_t st, int dist) {
+        if (MODE == MODE_PROJ || MODE == MODE_LAST) return (st & ORBM_MP_PRESENT) && (st & ORBM_MP_OBS);   // :113-115 / :1879-1881
+        if (MODE == MODE_INIT) return (int)st <= dist;                                                     // :608
+        return (st & ORBM_MP_PRESENT) != 0;                                                                // :2048 / :512
+    };
+    for (int j = tid; j < T; j += FUSED_THREADS) {
+        const v4f rc = F.cell_rec[j];
+        const uint32_t w = __float_as_uint(rc.w);
+        const int oct = (int)((w >> 16) & 15u), cy = (int)((w >> 20) & 63u), cx = (int)(w >> 26);
+        const int kp = (int)(w & 0xFFFFu);
+        c_rec[j] = v4f{rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17) | ((uint32_t)cy << 23))};
+        l_kp[j] = (uint16_t)kp;
+        // slot state, by stream position
+        uint32_t s0;
+        if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
+        else s0 = P.slot_flags ? P.slot_flags[(size_t)inst * P.stride + kp] : F.mp_flags[kp];
+        state[j] = s0;
+        owner[j] = -1;
+        post[j] = 0;
+        if (HIST_MODE) binmask[j] = 0;
+        const bool is_free = MODE == MODE_INIT || !is_blocked(s0, 0);
+        uint32_t p0 = 0xFFFFu, p1 = 0xFFFFu;
+        if (pairs) {
+            if (oct <= 7) p0 = bucket_add(s_base[oct] + (cx >> s_k[oct]) * ORBM_GRID_ROWS + cy);
+            if (oct + 1 <= 7) p1 = bucket_add(s_base[oct + 1] + (cx >> s_k[oct + 1]) * ORBM_GRID_ROWS + cy);
+        } else {
+            p0 = bucket_add((cx >> s_k[0]) * ORBM_GRID_ROWS + cy);
+        }
+        const int blk = (cy >> 2) * 16 + (cx >> 2);
+        const int s0i = pairs ? oct : 0, s1i = oct + 1;
+        if (p0 != 0xFFFFu) {
+            c_lst[p0] = (uint16_t)j;
+            if (is_free) {
+                atomicOr(&fbits[p0 >> 5], 1u << (p0 & 31));
+                atomicAdd(&fcnt[s0i * 96 + (blk >> 1)], 1u << (16 * (blk & 1)));
+                atomicOr(&fblk[s0i * 12 + (cy >> 2)], 1u << (cx >> 2));
+            }
+        }
+        if (p1 != 0xFFFFu) {
+            c_lst[p1] = (uint16_t)j;
+            if (is_free) {
+                atomicOr(&fbits[p1 >> 5], 1u << (p1 & 31));
+                atomicAdd(&fcnt[s1i * 96 + (blk >> 1)], 1u << (16 * (blk & 1)));
+                atomicOr(&fblk[s1i * 12 + (cy >> 2)], 1u << (cx >> 2));
+            }
+        }
+        l_pos[j] = (uint16_t)p0; l_pos[n4 + j] = (uint16_t)p1;
+    }
+    if (MODE == MODE_INIT) for (int i = tid; i < Q; i += FUSED_THREADS) out[i] = -1;     // vnMatches12 (:566)
+    if (tid < 36) s_hist[tid] = 0;
+    if (tid < 3) s_any[tid] = 0;
+    if (tid == 0) s_stamp_mem = 0;
+    __syncthreads();
+    {   // (counted after the scatter: its own pass, so that the counter's reset cannot race with the adds)
+        int nf = 0;
+        for (int j = tid; j < T; j += FUSED_THREADS) nf += (MODE == MODE_INIT || !is_blocked(state[j], 0)) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nf += __shfl_xor(nf, off, 64);
+        if (tid == 0) s_free_total = 0;
+        __syncthreads();
+        if (lane == 0 && nf) atomicAdd(&s_free_total, nf);
+        __syncthreads();
+    }
+
+    const bool use_hist = HIST_MODE && P.check_ori && (MODE == MODE_INIT || S.QS.angle != nullptr);
+    const bool stereo_gate = has_stereo_gate<MODE>(S);
+    const int thr = MODE == MODE_PROJ ? ORBM_TH_HIGH : (MODE == MODE_INIT ? ORBM_TH_LOW : P.dist_th);
+    const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
+    const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
+    auto wave_max = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    // every LDS / global access of this wave issued so far has completed and none issued later has started
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    int my_matches = 0;
+    // "does any thread of the workgroup ...?" with ONE barrier: three flags in rotation (as window_kernel)
+    int any_phase = 0;
+    auto wg_any = [&](bool pred) {
+        const int cur = any_phase % 3;
+        if (pred) s_any[cur] = 1;
+        if (tid == 0) s_any[(any_phase + 1) % 3] = 0;
+        lds_barrier();
+        any_phase++;
+        return s_any[cur] != 0;
+    };
+    // candidate words NW.. of a query, from its tail in global scratch (tcap is a multiple of 4)
+    auto load_tail = [&](uint32_t (&cc)[WIN_CACHE], gptr<const uint32_t> tailp, int tc) {
+        const gptr<const v4u> tq = (gptr<const v4u>)tailp;
+#pragma unroll
+        for (int g = 0; g < (WIN_CACHE - NW) / 4; g++)
+            if (tc > 4 * g) {
+                const v4u t4 = tq[g];
+                cc[NW + 4 * g] = t4.x;
+                cc[NW + 1 + 4 * g] = tc > 4 * g + 1 ? t4.y : W_INVALID;
+                cc[NW + 2 + 4 * g] = tc > 4 * g + 2 ? t4.z : W_INVALID;
+                cc[NW + 3 + 4 * g] = tc > 4 * g + 3 ? t4.w : W_INVALID;
+            }
+    };
+    // The rounds (evaluate / contested? / decide, see the top of the file) over one query per lane.  WIDE: every wave of the
+    // workgroup takes part (workgroup barriers between the phases, priority = position in the chunk); otherwise one wave on its
+    // own (wave-synchronous).  A post is (round stamp << 10 | 1023 - priority) under atomicMax: a lower-priority-number query
+    // of the same round wins, older rounds lose, the array is never cleared.  The stamp lives in LDS between calls.
+    auto rounds = [&](auto wide_tag, bool unresolved, int prio, int qi, uint32_t qflags, float qangle, int ncand2, uint32_t (&cc)[WIN_CACHE],
+                      gptr<const uint32_t> mytail) {
+        constexpr bool WIDE = decltype(wide_tag)::value;
+        auto sync = [&]() { if (WIDE) lds_barrier(); else wave_sync(); };
+        auto any = [&](bool p) { return WIDE ? wg_any(p) : (bool)__any(p); };
+        uint32_t rstamp = *s_stamp;                          // uniform: the last writer finished before the barrier that let us in
+        const int wave_ncand = wave_max(ncand2);
+        while (any(unresolved)) {
+            rstamp++;
+            const uint32_t mypost = (rstamp << 10) | (uint32_t)(1023 - prio);
+            auto lower_posted = [&](int k) {                 // has a lower-index unresolved query posted on slot k in this round?
+                const uint32_t v = post[k];
+                return (v >> 10) == rstamp && (1023u - (v & 1023u)) < (uint32_t)prio;
+            };
+            uint32_t bestW = W_INVALID, secondW = W_INVALID;
+            uint32_t freem = 0;                              // candidates (of the first WIN_CACHE) found free in this round
+            auto consider = [&](uint32_t w, uint32_t stv) {
+                const int k = (int)word_slot(w), dist = word_dist(w);
+                if (is_blocked(stv, dist)) return false;
+                if (dist <= thr) atomicMax(&post[k], mypost);                              // this query may still claim k
+                secondW = min(max(bestW, w), secondW);
+                bestW = min(bestW, w);
+                return true;
+            };
+            // ---- evaluate: the slot states of four candidates are requested together
+            if (unresolved) {
+                {
+#pragma unroll
+                    for (int g = 0; g < WIN_CACHE / 4; g++) {
+                        if (wave_ncand > 4 * g) {
+                            uint32_t stv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) stv[u] = 4 * g + u < ncand2 ? state[word_slot(cc[4 * g + u])] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (4 * g + u < ncand2 && consider(cc[4 * g + u], stv[u])) freem |= 1u << (4 * g + u);
+                        }
+                    }
+                    for (int i = WIN_CACHE; i < wave_ncand; i++)
+                        if (i < ncand2) { const uint32_t v = mytail[i - NW]; consider(v, state[word_slot(v)]); }
+                }
+            }
+            const int none = MODE == MODE_INIT ? INT_MAX : 256;
+            const bool has1 = word_valid(bestW), has2 = word_valid(secondW);
+            const int bestDist = has1 ? word_dist(bestW) : none, bestDist2 = has2 ? word_dist(secondW) : none;
+            const int bestIdx = has1 ? (int)word_slot(bestW) : -1, bestIdx2 = has2 ? (int)word_slot(secondW) : -1;
+            const int bestLevel = has1 ? word_oct(bestW) : -1, bestLevel2 = has2 ? word_oct(secondW) : -1;
+            const bool alive = unresolved && bestIdx >= 0 && bestDist <= thr;
+            // The second-best free slot enters the outcome through the ratio test only, and slots only ever become blocked, so
+            // its distance can only grow: a test that lets the query through now (bestDist <= ratio * bestDist2 for a6 --
+            // whatever the two levels are --, bestDist < bestDist2 * ratio for a5) lets it through with any later second best
+            // as well.  Only a query whose test does NOT pass on distances now depends on that slot staying free: it names it,
+            // so that no later query takes it first, and waits if a lower query may take it.
+            bool second_matters = false;
+            if (USES_SECOND && alive && bestIdx2 >= 0) {
+                if (MODE == MODE_PROJ) second_matters = (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2);
+                else second_matters = !((float)bestDist < __fmul_rn((float)bestDist2, P.ratio));
+            }
+            if (second_matters) atomicMax(&post[bestIdx2], mypost);
+            sync();
+            // ---- contested?
+            bool contested = false;
+            if (alive) {
+                contested = lower_posted(bestIdx);
+                if (second_matters && lower_posted(bestIdx2)) contested = true;
+            }
+            if (any(contested)) {
+                if (contested) {
+                    {
+#pragma unroll
+                        for (int i = 0; i < WIN_CACHE; i++)
+                            if ((freem >> i) & 1u) atomicMax(&post[word_slot(cc[i])], mypost);
+                        for (int i = WIN_CACHE; i < wave_ncand; i++)
+                            if (i < ncand2) {
+                                const uint32_t v = mytail[i - NW];
+                                const int k = (int)word_slot(v);
+                                if (!is_blocked(state[k], word_dist(v))) atomicMax(&post[k], mypost);
+                            }
+                    }
+                }
+                sync();
+            }
+            // ---- decide
+            if (unresolved) {
+                bool is_final = !alive;
+                if (alive && !contested) {
+                    bool accept0;
+                    if (MODE == MODE_PROJ) accept0 = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2));
+                    else if (MODE == MODE_INIT) accept0 = (float)bestDist < __fmul_rn((float)bestDist2, P.ratio);
+                    else accept0 = true;
+                    is_final = !accept0 || !lower_posted(bestIdx);
+                }
+                if (is_final) {
+                    unresolved = false;
+                    bool accept;
+                    if (MODE == MODE_PROJ)
+                        accept = bestDist <= ORBM_TH_HIGH &&
+                                 !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2));  // :153-158
+                    else if (MODE == MODE_INIT)
+                        accept = bestDist <= ORBM_TH_LOW && (float)bestDist < __fmul_rn((float)bestDist2, P.ratio);    // :625-627
+                    else
+                        accept = bestDist <= thr;                                         // :1904 / :2062 / :533
+                    if (accept) {
+                        const int bestKp = (int)l_kp[bestIdx];
+                        if (MODE == MODE_INIT) {
+                            const int old = owner[bestIdx];
+                            if (old >= 0) { out[old] = -1; my_matches--; }                 // :629-633
+                            out[qi] = bestKp; owner[bestIdx] = qi; state[bestIdx] = (uint32_t)bestDist;  // :636-638
+                        } else {
+                            uint32_t ns = ORBM_MP_PRESENT;
+                            if ((MODE != MODE_PROJ && MODE != MODE_LAST) || (qflags & ORBM_Q_OBS)) ns |= ORBM_MP_OBS;
+                            state[bestIdx] = ns;
+                            owner[bestIdx] = qi;                                           // :160 / :1906 / :2066 / :535
+                            if (is_blocked(ns, 0)) {                                       // the searching waves stop seeing the record
+                                const uint32_t p0 = l_pos[bestIdx], p1 = l_pos[n4 + bestIdx];
+                                const uint32_t rw = __float_as_uint(c_rec[bestIdx].w);
+                                const int roct = (int)((rw >> 13) & 15u), rcx = (int)((rw >> 17) & 63u), rcy = (int)((rw >> 23) & 63u);
+                                const int blk = (rcy >> 2) * 16 + (rcx >> 2);
+                                auto unfree = [&](uint32_t pp, int si) {
+                                    atomicAnd(&fbits[pp >> 5], ~(1u << (pp & 31)));
+                                    const uint32_t old = atomicSub(&fcnt[si * 96 + (blk >> 1)], 1u << (16 * (blk & 1)));
+                                    if (((old >> (16 * (blk & 1))) & 0xFFFFu) == 1u) atomicAnd(&fblk[si * 12 + (rcy >> 2)], ~(1u << (rcx >> 2)));
+                                };
+                                if (p0 != 0xFFFFu) unfree(p0, pairs ? roct : 0);
+                                if (p1 != 0xFFFFu) unfree(p1, roct + 1);
+                                atomicSub(&s_free_total, 1);
+                            }
+                        }
+                        my_matches++;
+                        if (use_hist) {
+                            const int bin = rot_bin(qangle, F.angle[bestKp]);              // :644-651 / :1911-1918 / :2079-2090
+                            atomicAdd(&hist[bin], 1);
+                            if (MODE != MODE_INIT) binmask[bestIdx] |= 1u << bin;
+                        }
+                    }
+                }
+            }
+            if (!WIDE) sync();      // (WIDE: the barrier of the loop condition orders the slot writes before the next round's reads)
+        }
+        // rstamp is uniform over the participants.  WIDE: everybody has passed the barrier of the last loop condition, and nobody
+        // reads the stamp again before the next chunk's barrier (B)
+        if (WIDE ? tid == 0 : lane == 0) *s_stamp = rstamp;
+    };
+
+#ifdef ORBM_DIAG
+    if (trace && inst == 0 && tid == 0) trace[1] = wall_clock64();
+#endif
+    const int n_chunks = (Q + FUSED_CHUNK - 1) / FUSED_CHUNK;
+    const int tid_c = tid - 64;                             // waves 1..15: the thread's query of a chunk
+    // The parameters of a query are requested PF chunks before its chunk is searched: a chunk takes about a microsecond once
+    // the frame's slots have filled up, a load from HBM three
+    constexpr int PF = MODE == MODE_PROJ ? 4 : 2;
+    RawQ rawq[PF];
+#pragma unroll
+    for (int d = 0; d < PF; d++) rawq[d] = raw_load<MODE>(P, S, wave > 0 ? d * FUSED_CHUNK + tid_c : Q);
+    for (int c = 0; c < n_chunks; c++) {
+        const int base_q = c * FUSED_CHUNK;
+        uint32_t *mytail_w = tail_scratch + ((size_t)(inst * 2 + (c & 1)) * FUSED_CHUNK + max(tid_c, 0)) * tcap;
+        uint32_t kw[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) kw[i] = W_INVALID;
+        int ncand = 0;
+        uint32_t mind = 0xFFFFu;
+        uint32_t meta_bits = 0, angle_bits = 0;
+        if (wave > 0) {
+            // ================= search: one query per lane =================
+            const int qi = base_q + tid_c;
+            Query q = raw_decode<MODE>(P, rawq[0], s_sf);
+#pragma unroll
+            for (int d = 0; d + 1 < PF; d++) rawq[d] = rawq[d + 1];
+            rawq[PF - 1] = raw_load<MODE>(P, S, qi + PF * FUSED_CHUNK);
+            const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
+            const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
+            const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
+            const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
+            const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
+            int lo = -1, hi = 255;
+            if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
+            else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+            meta_bits = (q.flags & ORBM_Q_OBS) ? 0x80000000u : 0u;
+            angle_bits = __float_as_uint(q.angle);
+            bool uncovered = false;
+            int st = 0;
+            bool covered = !pairs;
+            if (pairs && hi <= 7 && hi >= 0 && hi - lo <= 1) { st = hi; covered = true; }
+            bool more = q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0;
+            if (more && !covered) { uncovered = true; more = false; }
+            if (MODE != MODE_INIT && more) {
+                // is there a free record of this octave pair in any 4 x 4-cell block the window touches?  (four block rows
+                // at most are looked at; a taller window walks)
+                const int BY0 = y0 >> 2, BY1 = y1 >> 2;
+                const uint32_t colmask = ((2u << (x1 >> 2)) - 1u) & ~((1u << (x0 >> 2)) - 1u);
+                const uint32_t *fr = fblk + st * 12 + BY0;
+                uint32_t rows = fr[0];
+                if (BY1 >= BY0 + 1) rows |= fr[1];
+                if (BY1 >= BY0 + 2) rows |= fr[2];
+                if (BY1 >= BY0 + 3) rows |= fr[3];
+                if (BY1 <= BY0 + 3 && !(rows & colmask)) more = false;
+            }
+            const int kk = s_k[st], sb = s_base[st];
+            int X = (x0 >> kk) - 1;
+            const int X1 = x1 >> kk;
+            uint32_t j = 0, e = 0, fm = 0, jb = 0;          // list positions [j, e) of the column still to look at; fm = free records of [jb, jb + 32)
+            uint32_t park01 = 0;                            // FPARK stream positions, 16 bits each
+            int np = 0;
+            bool have_desc = false;
+            uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // distances of the parked survivors: the loads of all of them are requested together
+            auto flush = [&]() {
+                if (np > 0 && !have_desc) {
+                    load_desc<MODE>(S, qi, q);
+                    qd[0] = q.d0.x; qd[1] = q.d0.y; qd[2] = q.d0.z; qd[3] = q.d0.w; qd[4] = q.d1.x; qd[5] = q.d1.y; qd[6] = q.d1.z; qd[7] = q.d1.w;
+                    have_desc = true;
+                }
+                v4u dlo[FPARK], dhi[FPARK];
+                uint32_t ppos[FPARK], pw[FPARK];
+#pragma unroll
+                for (int i = 0; i < FPARK; i++) {
+                    ppos[i] = (i & 1) ? park01 >> 16 : park01 & 0xFFFFu;
+                    dlo[i] = dhi[i] = v4u{0, 0, 0, 0}; pw[i] = 0;
+                    if (i < np) {
+                        const int kp = (int)l_kp[ppos[i]];
+                        pw[i] = __float_as_uint(c_rec[ppos[i]].w);
+                        dlo[i] = gdesc[2 * kp]; dhi[i] = gdesc[2 * kp + 1];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FPARK; i++) {
+                    if (i < np) {
+                        const uint32_t cd[8] = {dlo[i].x, dlo[i].y, dlo[i].z, dlo[i].w, dhi[i].x, dhi[i].y, dhi[i].z, dhi[i].w};
+                        const uint32_t dist = hamming256(qd, cd);
+                        bool keepit = true;
+                        if (MODE == MODE_INIT) keepit = !((int)state[ppos[i]] <= (int)dist);        // :608, with the distance
+                        if (keepit) {
+                            const uint32_t x = (dist << 17) | (ppos[i] << 4) | ((pw[i] >> 13) & 15u);
+#pragma unroll
+                            for (int s2 = 0; s2 < NW; s2++) if (ncand == s2) kw[s2] = x;
+                            if (ncand >= NW && ncand < tcap + NW) mytail_w[ncand - NW] = x;
+                            mind = min(mind, dist);
+                            ncand++;
+                        }
+                    }
+                }
+                np = 0; park01 = 0;
+            };
+            for (;;) {
+                if (more) {
+                    if (fm == 0) {
+                        if (j >= e) {                       // next coarse column of the window
+                            if (++X > X1) more = false;
+                            else {
+                                const int b = sb + X * ORBM_GRID_ROWS;
+                                j = c_off[b + y0 + 1];
+                                e = c_off[b + y1 + 2];
+                            }
+                        }
+                        if (more && j < e) {                // the free records among the next 32 list positions
+                            const uint32_t w0 = fbits[j >> 5], w1 = fbits[(j >> 5) + 1];
+                            const uint32_t win = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (j & 31));
+                            const uint32_t len = e - j;
+                            fm = len >= 32 ? win : win & ((1u << len) - 1u);
+                            jb = j; j += 32;
+                        }
+                    }
+                    if (fm != 0) {
+                        const int bit = __ffs((int)fm) - 1;
+                        fm &= fm - 1;
+                        const uint32_t jcur = c_lst[jb + bit];
+                        const v4f rc = c_rec[jcur];
+                        const uint32_t w = __float_as_uint(rc.w);
+                        const int oct = (int)((w >> 13) & 15u), cx = (int)((w >> 17) & 63u);
+                        int pass = (int)(cx >= x0) & (int)(cx <= x1) & (int)(oct >= lo) & (int)(oct <= hi) &
+                                   (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
+                        if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
+                        if (pass) {
+                            park01 |= jcur << (16 * np);
+                            np++;
+                        }
+                    }
+                }
+                if (__any(np == FPARK)) flush();
+                if (!__any(more)) break;
+            }
+            if (__any(np > 0)) flush();
+            // more candidates than this form has words for (or a level range the index does not cover: cannot happen with the
+            // launch rules): the instance is flagged and searched again, whole, by the general kernel that follows this one
+            if (uncovered || ncand > tcap + NW) { *redo_flag = 1; ncand = min(ncand, tcap + NW); }
+        }
+        const bool live = wave > 0 && ncand > 0 && (int)mind <= thr;
+        const unsigned long long lmask = __ballot(live);
+        // tail words (global memory) written by this wave must have landed before another wave is told about them; a wave that
+        // wrote none keeps its outstanding loads in flight
+        if (__any(live && ncand > NW)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (wave > 0 && lane == 0) s_live[wave - 1] = lmask;
+        lds_barrier();                                      // (B) every wave's live mask is there; wave 0 has settled chunk c - 1
+#ifdef ORBM_DIAG
+        if (trace && inst == 0 && tid == 0 && c < 190) trace[800 + c] = wall_clock64();
+#endif
+        int L, before;                                      // live queries of the chunk; ... of the waves before this one
+        {
+            const int cw = lane < 15 ? (int)__popcll(s_live[lane]) : 0;
+            int incl = cw;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            L = __builtin_amdgcn_readlane(incl, 14);
+            before = wave >= 2 ? __shfl(incl, wave - 2, 64) : 0;
+        }
+        // no free slot is left in the frame and nothing is pending: every remaining query would skip every candidate
+        // (ORBmatcher.cc:113-115): the search is over
+        if (L == 0 && s_free_total == 0) break;
+        const gptr<const uint32_t> mytail_r = in_global(mytail_w);
+        if (L > NARROW_MAX) {
+            // ---- many live queries (the first chunks of an instance): every searching lane keeps its own query and the whole
+            // workgroup goes through the rounds together, claim priority = position in the chunk
+            uint32_t cc[WIN_CACHE];
+#pragma unroll
+            for (int i = 0; i < WIN_CACHE; i++) cc[i] = i < NW ? kw[i] : W_INVALID;
+            if (live && ncand > NW) load_tail(cc, mytail_r, ncand - NW);
+            rounds(std::true_type{}, live, max(tid_c, 0), base_q + tid_c, (meta_bits & 0x80000000u) ? ORBM_Q_OBS : 0u, __uint_as_float(angle_bits),
+                   live ? ncand : 0, cc, mytail_r);
+#ifdef ORBM_DIAG
+            if (trace && inst == 0 && tid == 0 && c < 250) { trace[2 + 2 * c] = wall_clock64(); trace[3 + 2 * c] = trace[2 + 2 * c]; trace[600 + c] = (unsigned long long)L; }
+#endif
+            continue;
+        }
+        // ---- few live queries: they go to wave 0 through the pending list, and the next chunk is searched meanwhile
+        if (live) {
+            const int rk = before + (int)__popcll(lmask & ((1ull << lane) - 1ull));
+            uint32_t *pe = pending + (size_t)rk * PEND_WORDS;
+            pe[0] = meta_bits | ((uint32_t)min(ncand, 0xFFFF) << 10) | (uint32_t)tid_c;
+            pe[1] = angle_bits;
+#pragma unroll
+            for (int i = 0; i < NW; i++) pe[2 + i] = kw[i];
+        }
+        lds_barrier();                                      // (A) the pending list of chunk c is complete
+#ifdef ORBM_DIAG
+        if (trace && inst == 0 && tid == 0 && c < 250) trace[2 + 2 * c] = wall_clock64();
+#endif
+        if (wave != 0) continue;
+        if (L > 0) {
+            const bool mine = lane < L;
+            uint32_t cc[WIN_CACHE];
+#pragma unroll
+            for (int i = 0; i < WIN_CACHE; i++) cc[i] = W_INVALID;
+            uint32_t meta = 0, abits = 0;
+            if (mine) {
+                const uint32_t *pe = pending + (size_t)lane * PEND_WORDS;
+                meta = pe[0]; abits = pe[1];
+#pragma unroll
+                for (int i = 0; i < NW; i++) cc[i] = pe[2 + i];
+            }
+            const int t_c = (int)(meta & 1023u);
+            const int ncand2 = mine ? (int)((meta >> 10) & 0xFFFFu) : 0;
+            const gptr<const uint32_t> mytail = in_global(tail_scratch) + ((size_t)(inst * 2 + (c & 1)) * FUSED_CHUNK + t_c) * tcap;
+            if (__any(mine && ncand2 > NW)) {
+                if (mine && ncand2 > NW) load_tail(cc, mytail, ncand2 - NW);
+            }
+            rounds(std::false_type{}, mine, lane, base_q + t_c, (meta & 0x80000000u) ? ORBM_Q_OBS : 0u, __uint_as_float(abits), ncand2, cc, mytail);
+        }
+#ifdef ORBM_DIAG
+        if (trace && inst == 0 && tid == 0 && c < 250) { trace[3 + 2 * c] = wall_clock64(); trace[600 + c] = (unsigned long long)L; }
+#endif
+    }
+#ifdef ORBM_DIAG
+    if (trace && inst == 0 && tid == 0) trace[599] = wall_clock64();
+#endif
+    if (my_matches) atomicAdd(nmatch, my_matches);
+    __syncthreads();
+    // a flagged instance is searched again from the beginning by the kernel that follows: nothing of this attempt may reach
+    // the outputs (prev_xy of SearchForInitialization is an input of that pass as well)
+    if (*redo_flag != 0) return;
+    if (use_hist) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(hist, i1, i2, i3);
+            keep[0] = i1; keep[1] = i2; keep[2] = i3;
+            if (MODE != MODE_INIT) {
+                int drop = 0;
+                for (int b = 0; b < ORBM_HISTO_LENGTH; b++)
+                    if (b != i1 && b != i2 && b != i3) drop += hist[b];
+                *nmatch -= drop;
+            }
+        }
+        __syncthreads();
+        const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
+        uint32_t keepmask = 0;
+        if (k1 >= 0) keepmask |= 1u << k1;
+        if (k2 >= 0) keepmask |= 1u << k2;
+        if (k3 >= 0) keepmask |= 1u << k3;
+        if (MODE == MODE_INIT) {
+            int removed = 0;
+            for (int i = tid; i < Q; i += FUSED_THREADS) {
+                const int m = out[i];
+                if (m < 0) continue;                                                      // :673 (a stolen match is already -1)
+                const int bin = rot_bin(S.F1.angle[i], F.angle[m]);
+                if (!((keepmask >> bin) & 1u)) { out[i] = -1; removed++; }
+            }
+            if (removed) atomicSub(nmatch, removed);
+        } else {
+            for (int i = tid; i < T; i += FUSED_THREADS)
+                if (binmask[i] & ~keepmask) owner[i] = -2;                                 // slot set to NULL (:1942 / :2115)
+        }
+        __syncthreads();
+    }
+    if (MODE == MODE_INIT) {
+        for (int i = tid; i < Q; i += FUSED_THREADS) {                                    // :684-686
+            const int m = out[i];
+            if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
+        }
+    } else {
+        for (int i = tid; i < n; i += FUSED_THREADS) out[i] = -1;                         // keypoints outside the grid are never candidates
+        __syncthreads();
+        for (int i = tid; i < T; i += FUSED_THREADS) out[l_kp[i]] = owner[i];
+    }
+    if (tid == 0) P.counts[inst] = *nmatch;
+}
+
 // ---- the claim loop.  PRE = false: collects inline (one kernel does everything; frame optionally staged in LDS).
 // PRE = true: kernel 2 of 2 of the split form, candidates come from collect_kernel's rows.
 template <int MODE, bool LDS_FRAME, bool PRE>
-__global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const uint32_t *tail_in, int tcap) {
+__global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_in, const uint32_t *tail_in, int tcap, const int32_t *redo_flags) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_any[3];
     const int inst = blockIdx.x;
+    // as the pass after fused_kernel: only the instances that kernel flagged (a query with more candidates than it holds) are
+    // searched, from the beginning; the others leave at once
+    if (redo_flags && redo_flags[inst] == 0) return;
     const FrameG F(P.frames[P.frame_ids[inst]]);
     const int n = F.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1012,14 +1740,14 @@ constexpr int WIN_LDS_FRAME_MAX_N = 2200;   // cell_off + 16 B records + 32 B de
 
 template <int MODE, bool LDS_FRAME, bool PRE>
 int launch_claims(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int threads, int waves_per_inst,
-                  const v4u *head, const uint32_t *tail, int tcap = 0) {
+                  const v4u *head, const uint32_t *tail, int tcap = 0, const int32_t *redo_flags = nullptr) {
     const size_t lds = ((size_t)(LDS_FRAME ? 3076 + 12 * (size_t)max_n : 0) + 5 * (size_t)max_n + 64 +
                         (PRE ? SCAN_U * threads / 2 + 2 * (SCAN_U * 16 + 1) : 0)) * 4;
     if (lds > 160 * 1024)
         return orbm_fail(ctx, ORBM_ELIMIT, "windowed search: frames of %d keypoints need %zu bytes of LDS slot state (limit 163840)", max_n, lds);
     HIPCHK(ctx, (orbm_allow_dynamic_lds<&window_kernel<MODE, LDS_FRAME, PRE>>(ctx, lds)));
     hipLaunchKernelGGL((window_kernel<MODE, LDS_FRAME, PRE>), dim3(n_inst), dim3(threads), lds, ctx->stream, P,
-                       waves_per_inst, head, tail, tcap);
+                       waves_per_inst, head, tail, tcap, redo_flags);
     HIPCHK(ctx, hipGetLastError());
     return ORBM_OK;
 }
@@ -1059,7 +1787,10 @@ static size_t collect_lds_bytes(const CoarseCfg &c, bool desc_lds) {
 
 // tuning / test knob: 0 = split form (collect_kernel + claims), 1 = single kernel with the frame staged in LDS,
 // 2 = single kernel reading the frame from global memory
+// 3 = the fused form (one launch per batch) wherever it fits, 4 = never the fused form; 0 = by batch shape:
 int g_win_variant = 0;
+int g_win_fused_min_inst = 32;     // fused from this many instances per call ...
+int g_win_fused_max_q = 4096;      // ... or when no query set of the call is larger than this
 int g_win_cost_exact = 1;   // cost classes of collect_kernel: 1 = the walk's exact trip count, 0 = window area (A/B knob)
 
 template <int MODE>
@@ -1077,7 +1808,69 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     if (!PAIRS) rmax[0] = 20.0f;
     const CoarseCfg cfg = coarse_cfg(PAIRS, rmax, max_n);
     // frames too large for collect_kernel's LDS index (or with more than 8 pyramid levels) use the single-kernel form
-    const bool single = g_win_variant != 0 || collect_lds_bytes(cfg, false) > 160 * 1024 || max_n > 8191 || (PAIRS && max_levels > 8);
+    const bool index_ok = max_n <= 8191 && !(PAIRS && max_levels > 8);
+    const bool single = g_win_variant == 1 || g_win_variant == 2 || collect_lds_bytes(cfg, false) > 160 * 1024 || !index_ok;
+    // the fused form (one launch, one workgroup per instance): batches that give the chip an instance per CU or so, and calls
+    // with few queries (a tracking frame: one launch instead of two, no scratch round trip); a single large query set alone is
+    // spread over the chip by the split form instead
+    constexpr bool BINMASK = MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT;
+    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK);
+    const bool fused_fits = index_ok && fused_lds <= 160 * 1024 && max_q > 0;
+    if (fused_fits && g_win_variant != 1 && g_win_variant != 2 && g_win_variant != 4 &&
+        (g_win_variant == 3 || n_inst >= g_win_fused_min_inst || max_q <= g_win_fused_max_q)) {
+        constexpr size_t WIN_SCRATCH_CAP = (size_t)1 << 30;
+        int tcap = 60;
+        while (tcap > 12 && (size_t)n_inst * 2 * FUSED_CHUNK * tcap * 4 > WIN_SCRATCH_CAP) tcap -= 16;
+        const size_t inst_bytes = (size_t)2 * FUSED_CHUNK * tcap * 4;
+        const int run_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_inst, WIN_SCRATCH_CAP / inst_bytes));
+        const size_t o_flags = ((size_t)run_max * inst_bytes + 255) & ~(size_t)255, o_trace = o_flags + (((size_t)run_max * 4 + 255) & ~(size_t)255);
+        int rc = orbm_ws2_reserve(ctx, o_trace + 16384);
+        if (rc) return rc;
+        // the pass that searches flagged instances again (the general single-kernel form reading global memory) must be launchable
+        if (((size_t)5 * max_n + 64) * 4 > 160 * 1024) return orbm_fail(ctx, ORBM_ELIMIT, "windowed search: frames of %d keypoints are not supported", max_n);
+        HIPCHK(ctx, (orbm_allow_dynamic_lds<&fused_kernel<MODE>>(ctx, fused_lds)));
+        for (int i0 = 0; i0 < n_inst; i0 += run_max) {
+            const int ni = std::min(run_max, n_inst - i0);
+            WinParams R = P;
+            R.frame_ids += i0; R.qset_ids += i0; R.out += (size_t)i0 * P.stride; R.counts += i0;
+            if (R.slot_flags) R.slot_flags += (size_t)i0 * P.stride;
+            unsigned long long *trace = nullptr;
+#ifdef ORBM_DIAG
+            static const bool want_trace = getenv("ORBM_WIN_TRACE") != nullptr;
+            if (want_trace) {                                  // timestamps of instance 0, after the tail scratch
+                trace = (unsigned long long *)((char *)ctx->ws2 + o_trace);
+                HIPCHK(ctx, hipMemsetAsync(trace, 0, 16384, ctx->stream));
+            }
+#endif
+            int32_t *redo = (int32_t *)((char *)ctx->ws2 + o_flags);
+            hipLaunchKernelGGL((fused_kernel<MODE>), dim3((unsigned)ni), dim3(FUSED_THREADS), fused_lds, ctx->stream, R, cfg, (uint32_t *)ctx->ws2, tcap, redo, trace);
+            HIPCHK(ctx, hipGetLastError());
+            // instances with a query that has more candidates than the fused form holds (tcap + 8: very wide windows over crowded
+            // keypoints) are searched again by the general form; everywhere else its workgroups return at once
+            rc = launch_claims<MODE, false, false>(ctx, R, ni, max_n, MODE == MODE_INIT ? 256 : 512, 0, nullptr, nullptr, 0, redo);
+            if (rc) return rc;
+#ifdef ORBM_DIAG
+            if (want_trace) {
+                static unsigned long long h[2048];
+                HIPCHK(ctx, hipMemcpyAsync(h, trace, 16384, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "[fused trace] index %.2f us, total %.2f us; per chunk (search+handoff us | claims us | live):", (h[1] - h[0]) / 100.0, (h[599] - h[0]) / 100.0);
+                unsigned long long prev = h[1];
+                for (int c = 0; c < 250 && h[2 + 2 * c]; c++) {
+                    fprintf(stderr, " [%d: %.2f (search %.2f) | %.2f | %llu]", c, (h[2 + 2 * c] - prev) / 100.0, c < 190 ? (h[800 + c] - prev) / 100.0 : 0.0,
+                            (h[3 + 2 * c] - h[2 + 2 * c]) / 100.0, h[600 + c]);
+                    prev = h[2 + 2 * c];
+                }
+                fprintf(stderr, "\n[fused trace] chunk 0 batches (load us | rounds us | rounds | widest list):");
+                for (int b = 0; b < 15 && h[1000 + 4 * b]; b++)
+                    fprintf(stderr, " [%.2f | %.2f | %llu | %llu]", (h[1001 + 4 * b] - h[1000 + 4 * b]) / 100.0, (h[1002 + 4 * b] - h[1001 + 4 * b]) / 100.0,
+                            h[1003 + 4 * b] & 0xFFFFFFFFull, h[1003 + 4 * b] >> 32);
+                fprintf(stderr, "\n");
+            }
+#endif
+        }
+        return ORBM_OK;
+    }
     if (single) {
         if (max_n <= WIN_LDS_FRAME_MAX_N && g_win_variant != 2)
             return launch_claims<MODE, true, false>(ctx, P, n_inst, max_n, MODE == MODE_INIT ? 256 : 1024, 0, nullptr, nullptr);
@@ -1207,6 +2000,7 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
 
 // tuning / test knob (not part of the public ABI): see g_win_variant
 extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
+extern "C" void orbm__window_fused_rule(int min_inst, int max_q) { g_win_fused_min_inst = min_inst; g_win_fused_max_q = max_q; }
 #ifdef ORBM_DIAG
 // phase-timing diagnostics of collect_kernel (bits 1-3 switch phases off: wrong results); only in `make diag` builds
 extern "C" void orbm__window_cost_exact(int v) { g_win_cost_exact = v; }

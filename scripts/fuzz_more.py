@@ -12,6 +12,7 @@ import test_gpu_search as T
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 FORMS = tuple(int(x) for x in os.environ.get('ORBM_FUZZ_FORMS', '1,2,5').split(','))
+WIN_FORMS = tuple(int(x) for x in os.environ.get('ORBM_FUZZ_WIN_FORMS', '3,4').split(','))
 ONLY_BOW = os.environ.get('ORBM_FUZZ_ONLY_BOW') == '1'
 orc.lib()
 ctx = Context(0)
@@ -19,7 +20,8 @@ t0 = time.time()
 for s in range(first, first + n_seeds):
     os.environ["ORBM_FUZZ_SEED"] = str(1000 * s)
     if not ONLY_BOW:
-        T.test_claim_rounds_fuzz_near_thresholds(ctx, orc)
+        for wv in WIN_FORMS:                      # 3 = fused form of the windowed searches, 4 = split form
+            T.test_claim_rounds_fuzz_near_thresholds(ctx, orc, wv)
     for form in FORMS:
         T.test_bow_fuzz_near_thresholds(ctx, orc, form)
         T.test_triang_fuzz_crowded_nodes(ctx, orc, form)

@@ -367,10 +367,11 @@ def test_search_init_steals(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
-    """The windowed searches have three forms (split collect + claims = default, single kernel with the frame in LDS,
-    single kernel reading global memory; frames above 2200 keypoints never use LDS staging): same results."""
+    """The windowed searches have four forms (0 = chosen by batch shape; 3 = fused: one launch, a workgroup per instance searches
+    and settles claims; 4 = split: collect + claims kernels; 1 = single kernel with the frame in LDS; 2 = single kernel reading
+    global memory; frames above 2200 keypoints never use LDS staging): same results."""
     from orbslam2_amd import _lib
     L = _lib.load()
     try:
@@ -578,7 +579,7 @@ def test_proj_second_best_above_threshold_is_not_claimed_early(ctx, orc):
         wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8)
         assert wo[0] == pad and wo[1] == -1 and wo[2] == pad + 2 and wo[3] == -1 and wc == 2      # a <- i, b free, c <- k
         fid = ctx.upload_frames([f]); qid = ctx.upload_proj_queries([q])
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3, 4):
             from orbslam2_amd import _lib
             _lib.load().orbm__window_variant(variant)
             try:
@@ -596,8 +597,8 @@ def _dense_frame(rng, n, lm_desc):
                             mp_flags=np.where(rng.random(n) < 0.1, MP_PRESENT | MP_OBS, 0).astype(np.uint8)), lm
 
 
-def test_claim_rounds_fuzz_near_thresholds(ctx, orc):
-    """Many small, crowded instances whose query-to-keypoint distances straddle the acceptance thresholds and whose
+def _claim_rounds_fuzz(ctx, orc):
+    """(fused and split form of the windowed searches.)  Many small, crowded instances whose query-to-keypoint distances straddle the acceptance thresholds and whose
     windows overlap almost completely: the in-order claim rules decide nearly every match (a6 with its ratio test on
     the second-best, a11 best-only, a5 with stealing)."""
     rng = np.random.default_rng(2024 + _fuzz_offset())
@@ -651,6 +652,16 @@ def test_claim_rounds_fuzz_near_thresholds(ctx, orc):
             wc, wm, wprev, _ = orc.search_init(f1, f2, prev, 100, ratio, True)
             assert cnt == wc and np.array_equal(m12, wm) and np.array_equal(prev_out, wprev), ("init", trial, ratio)
         ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("win_variant", [3, 4])
+def test_claim_rounds_fuzz_near_thresholds(ctx, orc, win_variant):
+    from orbslam2_amd import _lib
+    _lib.load().orbm__window_variant(win_variant)
+    try:
+        _claim_rounds_fuzz(ctx, orc)
+    finally:
+        _lib.load().orbm__window_variant(0)
 
 
 @pytest.mark.parametrize("form", [1, 2, 5])
