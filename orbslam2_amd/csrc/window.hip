@@ -524,13 +524,14 @@ constexpr int FUSED_CHUNK = FUSED_THREADS - 64;   // queries per chunk: waves 1.
 constexpr int PEND_WORDS = 10;                    // pending entry: meta, the query's angle, eight candidate words
 constexpr int FPARK = 2;                          // survivors a lane parks (in registers) between two distance passes
 
-static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask) {
+static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask, bool desc_lds) {
     const int total = c.base[c.nstruct];
     const size_t offn = (size_t)((total + 6) & ~1);
     const size_t n4 = (size_t)((c.n_cap + 3) & ~3);
     return (((offn / 2 + 3) & ~(size_t)3)) * 4 + n4 * 16 + (size_t)((c.rec_cap + 7) & ~7) * 2 + (size_t)((c.n_cap + 7) & ~7) * 2 +
-           n4 * 4 * (3 + (with_binmask ? 1 : 0)) + (size_t)64 * PEND_WORDS * 4 + n4 * 4 /* l_pos */ +
-           (size_t)(((c.rec_cap + 31) / 32 + 4) & ~3) * 4 /* fbits */ + (8 * 12 + 8 * 96) * 4 /* fblk, fcnt */ + 64;
+           n4 * 4 * (3 + (with_binmask ? 1 : 0)) + (size_t)64 * PEND_WORDS * 4 +
+           (size_t)(((c.rec_cap + 31) / 32 + 4) & ~3) * 4 /* fbits */ + (8 * 12 + 8 * 96) * 4 /* fblk, fcnt */ + 64 +
+           (desc_lds ? (size_t)c.n_cap * 32 + 16 : 0);
 }
 
 // raw per-query parameters as loaded (requested a chunk ahead), decoded when the chunk is searched
@@ -609,7 +610,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, CoarseCfg cfg, uint32_t *tail_scratch, int tcap, int32_t *redo_flags, unsigned long long *trace) {
+__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, CoarseCfg cfg, uint32_t *tail_scratch, int tcap, int32_t *redo_flags, int desc_lds,
+                                                                unsigned long long *trace) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[FUSED_THREADS / 64];
@@ -643,12 +645,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
     uint32_t *post = state + 2 * (size_t)n4;
     uint32_t *binmask = state + 3 * (size_t)n4;                                   // HIST_MODE only
     uint32_t *pending = state + (3 + (HIST_MODE ? 1 : 0)) * (size_t)n4;
-    uint16_t *l_pos = reinterpret_cast<uint16_t *>(pending + (size_t)64 * PEND_WORDS);   // [2][n4]: where stream position j sits in c_lst (0xFFFF: nowhere)
-    uint32_t *fbits = reinterpret_cast<uint32_t *>(l_pos + 2 * (size_t)n4);       // bit p: the record at c_lst[p] is free (not blocked)
+    uint32_t *fbits = pending + (size_t)64 * PEND_WORDS;                          // bit p: the record at c_lst[p] is free (not blocked)
     // fblk[s * 12 + BY] bit BX: structure s holds a free record in the block of 4 x 4 grid cells (BX, BY); fcnt = how many
     // (two 16-bit counters per word).  A query whose window touches no such block is finished without a walk.
     uint32_t *fblk = fbits + fwords;
     uint32_t *fcnt = fblk + 8 * 12;
+    v4u *l_desc = reinterpret_cast<v4u *>(fcnt + 8 * 96 + 4);                     // desc_lds: the frame's descriptors by stream position
     int *hist = s_hist, *nmatch = s_hist + 32, *keep = s_hist + 33;
 #ifdef ORBM_DIAG
     if (trace && inst == 0 && tid == 0) trace[0] = wall_clock64();
@@ -712,6 +714,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
         const int kp = (int)(w & 0xFFFFu);
         c_rec[j] = v4f{rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17) | ((uint32_t)cy << 23))};
         l_kp[j] = (uint16_t)kp;
+        if (desc_lds) {
+            const gptr<const v4u> gd = (gptr<const v4u>)F.desc;
+            l_desc[2 * j] = gd[2 * kp]; l_desc[2 * j + 1] = gd[2 * kp + 1];
+        }
         // slot state, by stream position
         uint32_t s0;
         if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                 atomicOr(&fblk[s1i * 12 + (cy >> 2)], 1u << (cx >> 2));
             }
         }
-        l_pos[j] = (uint16_t)p0; l_pos[n4 + j] = (uint16_t)p1;
+
     }
     if (MODE == MODE_INIT) for (int i = tid; i < Q; i += FUSED_THREADS) out[i] = -1;     // vnMatches12 (:566)
     if (tid < 36) s_hist[tid] = 0;
@@ -921,17 +927,25 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                             state[bestIdx] = ns;
                             owner[bestIdx] = qi;                                           // :160 / :1906 / :2066 / :535
                             if (is_blocked(ns, 0)) {                                       // the searching waves stop seeing the record
-                                const uint32_t p0 = l_pos[bestIdx], p1 = l_pos[n4 + bestIdx];
+                                // where the record sits in the lists of its (up to two) structures: found by walking its bucket's
+                                // short run (a claim is rare next to a search; a table of positions would cost 4 B of LDS per keypoint)
                                 const uint32_t rw = __float_as_uint(c_rec[bestIdx].w);
                                 const int roct = (int)((rw >> 13) & 15u), rcx = (int)((rw >> 17) & 63u), rcy = (int)((rw >> 23) & 63u);
                                 const int blk = (rcy >> 2) * 16 + (rcx >> 2);
-                                auto unfree = [&](uint32_t pp, int si) {
-                                    atomicAnd(&fbits[pp >> 5], ~(1u << (pp & 31)));
+                                auto unfree = [&](int si) {
+                                    const int b = s_base[si] + (rcx >> s_k[si]) * ORBM_GRID_ROWS + rcy;
+                                    uint32_t pp = c_off[b + 1];
+                                    const uint32_t pe = c_off[b + 2];
+                                    while (pp < pe && c_lst[pp] != (uint16_t)bestIdx) pp++;
+                                    if (pp < pe) atomicAnd(&fbits[pp >> 5], ~(1u << (pp & 31)));
                                     const uint32_t old = atomicSub(&fcnt[si * 96 + (blk >> 1)], 1u << (16 * (blk & 1)));
                                     if (((old >> (16 * (blk & 1))) & 0xFFFFu) == 1u) atomicAnd(&fblk[si * 12 + (rcy >> 2)], ~(1u << (rcx >> 2)));
                                 };
-                                if (p0 != 0xFFFFu) unfree(p0, pairs ? roct : 0);
-                                if (p1 != 0xFFFFu) unfree(p1, roct + 1);
+                                if (!pairs) unfree(0);
+                                else {
+                                    if (roct <= 7) unfree(roct);
+                                    if (roct + 1 <= 7) unfree(roct + 1);
+                                }
                                 atomicSub(&s_free_total, 1);
                             }
                         }
@@ -1012,8 +1026,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
             uint32_t j = 0, e = 0, fm = 0, jb = 0;          // list positions [j, e) of the column still to look at; fm = free records of [jb, jb + 32)
             uint32_t park01 = 0;                            // FPARK stream positions, 16 bits each
             int np = 0;
+            // the query's own descriptor is requested now (it travels while the window is walked) -- only for queries whose
+            // window holds a free record at all
             bool have_desc = false;
             uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (more) {
+                load_desc<MODE>(S, qi, q);
+                qd[0] = q.d0.x; qd[1] = q.d0.y; qd[2] = q.d0.z; qd[3] = q.d0.w; qd[4] = q.d1.x; qd[5] = q.d1.y; qd[6] = q.d1.z; qd[7] = q.d1.w;
+                have_desc = true;
+            }
             // distances of the parked survivors: the loads of all of them are requested together
             auto flush = [&]() {
                 if (np > 0 && !have_desc) {
@@ -1028,9 +1049,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                     ppos[i] = (i & 1) ? park01 >> 16 : park01 & 0xFFFFu;
                     dlo[i] = dhi[i] = v4u{0, 0, 0, 0}; pw[i] = 0;
                     if (i < np) {
-                        const int kp = (int)l_kp[ppos[i]];
                         pw[i] = __float_as_uint(c_rec[ppos[i]].w);
-                        dlo[i] = gdesc[2 * kp]; dhi[i] = gdesc[2 * kp + 1];
+                        if (desc_lds) { dlo[i] = l_desc[2 * ppos[i]]; dhi[i] = l_desc[2 * ppos[i] + 1]; }
+                        else { const int kp = (int)l_kp[ppos[i]]; dlo[i] = gdesc[2 * kp]; dhi[i] = gdesc[2 * kp + 1]; }
                     }
                 }
 #pragma unroll
@@ -1789,8 +1810,11 @@ static size_t collect_lds_bytes(const CoarseCfg &c, bool desc_lds) {
 // 2 = single kernel reading the frame from global memory
 // 3 = the fused form (one launch per batch) wherever it fits, 4 = never the fused form; 0 = by batch shape:
 int g_win_variant = 0;
-int g_win_fused_min_inst = 32;     // fused from this many instances per call ...
-int g_win_fused_max_q = 4096;      // ... or when no query set of the call is larger than this
+// (measured, scripts/track_perf.py + proj_fused_perf.py: one instance alone is faster split -- its search spreads over the
+// chip, 0.076 against 0.112 ms for 1500 queries -- except SearchForInitialization, whose long claim chains dominate; a batch
+// is faster fused from a few dozen instances on: 256 x 50k queries 0.24 against 0.88 ms)
+int g_win_fused_min_inst = 48;     // fused from this many instances per call ...
+int g_win_fused_max_q = 0;         // ... or when no query set of the call is larger than this (0: never by size)
 int g_win_cost_exact = 1;   // cost classes of collect_kernel: 1 = the walk's exact trip count, 0 = window area (A/B knob)
 
 template <int MODE>
@@ -1814,10 +1838,14 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     // with few queries (a tracking frame: one launch instead of two, no scratch round trip); a single large query set alone is
     // spread over the chip by the split form instead
     constexpr bool BINMASK = MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT;
-    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK);
-    const bool fused_fits = index_ok && fused_lds <= 160 * 1024 && max_q > 0;
+    constexpr size_t FUSED_LDS_MAX = 160 * 1024 - 1024;       // dynamic part: the kernel's static __shared__ arrays take the rest
+    // (the kernel can keep the frame's descriptors in LDS too; measured no faster -- the search of the first chunks is bound by
+    // instruction issue, not by the candidate gathers -- so the 32 B per keypoint stay free for larger frames)
+    const bool fused_desc_lds = false;
+    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK, fused_desc_lds);
+    const bool fused_fits = index_ok && fused_lds <= FUSED_LDS_MAX && max_q > 0;
     if (fused_fits && g_win_variant != 1 && g_win_variant != 2 && g_win_variant != 4 &&
-        (g_win_variant == 3 || n_inst >= g_win_fused_min_inst || max_q <= g_win_fused_max_q)) {
+        (g_win_variant == 3 || MODE == MODE_INIT || n_inst >= g_win_fused_min_inst || max_q <= g_win_fused_max_q)) {
         constexpr size_t WIN_SCRATCH_CAP = (size_t)1 << 30;
         int tcap = 60;
         while (tcap > 12 && (size_t)n_inst * 2 * FUSED_CHUNK * tcap * 4 > WIN_SCRATCH_CAP) tcap -= 16;
@@ -1843,7 +1871,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
             }
 #endif
             int32_t *redo = (int32_t *)((char *)ctx->ws2 + o_flags);
-            hipLaunchKernelGGL((fused_kernel<MODE>), dim3((unsigned)ni), dim3(FUSED_THREADS), fused_lds, ctx->stream, R, cfg, (uint32_t *)ctx->ws2, tcap, redo, trace);
+            hipLaunchKernelGGL((fused_kernel<MODE>), dim3((unsigned)ni), dim3(FUSED_THREADS), fused_lds, ctx->stream, R, cfg, (uint32_t *)ctx->ws2, tcap, redo, fused_desc_lds ? 1 : 0, trace);
             HIPCHK(ctx, hipGetLastError());
             // instances with a query that has more candidates than the fused form holds (tcap + 8: very wide windows over crowded
             // keypoints) are searched again by the general form; everywhere else its workgroups return at once
