@@ -276,6 +276,17 @@ int orbm_pack_records(orbm_ctx *ctx, int n_pairs, const uint32_t *pair_id, const
 int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                         const uint32_t *pair_id, float ratio, int th, int check_ori, int32_t stride, int threshold,
                         orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap, uint32_t *totals, int io_on_device);
+/* The same over SEVERAL GPUs from one host process (SURVEY 8(b) `orbm_allpairs(ctx[], n_gpus, ...)`; the reference's
+ * candidate loops LoopClosing.cc:433-477, Tracking.cc:1778-1801 run over shards).  ctxs[0 .. n_ctx): one context per GPU (or
+ * several on one GPU), handles[c][k] = handle of keyframe k in context c (every context holds the keyframes it is given;
+ * a store replicated with orbm_frames_upload in each context has the same handles everywhere).  kf_a / kf_b name
+ * keyframes by k; all arrays are HOST memory.  The pair list is cut into n_ctx contiguous slices, one worker thread per
+ * context matches its slice (orbm_allpairs_batch) and the records are concatenated in pair order: the result equals one
+ * context's for the whole list.  No collective is involved.  Errors: the failing context's code; its message is copied to
+ * ctxs[0]. */
+int orbm_allpairs(orbm_ctx *const *ctxs, int n_ctx, const int32_t *const *handles, int kind, int n_pairs, const int32_t *kf_a,
+                  const int32_t *kf_b, const uint32_t *pair_id, float ratio, int th, int check_ori, int32_t stride, int threshold,
+                  orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap, uint32_t *totals);
 /* Block-cyclic sharding of the pair triangle {(a, b): 0 <= a < b < n_kf} over `world` GPUs (host arithmetic, no context):
  * the triangle is cut into tile x tile blocks of keyframes (row-major over the upper-triangular blocks), block k belongs to
  * rank k % world, pairs inside a block ascend in a, then b: a block's pairs touch 2 x tile keyframes, whose descriptors sit

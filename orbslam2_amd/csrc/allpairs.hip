@@ -8,6 +8,8 @@
 //   * (u16 idx1, u16 idx2) x nmatches, ascending idx1, ONLY for pairs with nmatches >= threshold, pair after pair in
 //     batch order (the receiver finds a pair's list by a running sum over the summaries).
 #include <algorithm>
+#include <string.h>
+#include <thread>
 #include "orbm_internal.h"
 
 namespace {
@@ -204,6 +206,63 @@ int orbm_allpairs_batch(orbm_ctx *ctx, int kind, int n_pairs, const int32_t *fra
                            (const FrameDev *)ctx->d_frames, (const int32_t *)(kind == 2 ? dfb : dfa));   // rows beyond the frame's n are never read
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
+}
+
+
+// SURVEY 8(b) `orbm_allpairs(ctx[], n_gpus, ...)`: the pair loop of LoopClosing.cc:433-477 / Tracking.cc:1778-1801 over
+// several GPUs from ONE host process.  Pairs are independent, so the list is cut into n_ctx contiguous slices, one worker
+// thread per context runs orbm_allpairs_batch on its slice (host-memory I/O), and the records are concatenated in pair
+// order: exactly the records one context would have produced for the whole list.  No collective: every context holds the
+// keyframes its slice touches (handles[c][k] = handle of keyframe k in context c).
+int orbm_allpairs(orbm_ctx *const *ctxs, int n_ctx, const int32_t *const *handles, int kind, int n_pairs, const int32_t *kf_a,
+                  const int32_t *kf_b, const uint32_t *pair_id, float ratio, int th, int check_ori, int32_t stride, int threshold,
+                  orbm_pair_summary *summaries, uint32_t *lists, uint32_t list_cap, uint32_t *totals) {
+    if (!ctxs || n_ctx <= 0 || !ctxs[0]) return ORBM_EINVAL;
+    orbm_ctx *c0 = ctxs[0];
+    for (int c = 0; c < n_ctx; c++)
+        if (!ctxs[c] || !handles || !handles[c]) return orbm_fail(c0, ORBM_EINVAL, "allpairs: context or handle table %d is null", c);
+    if (n_pairs < 0 || stride < 0 || (n_pairs > 0 && (!kf_a || !kf_b || !summaries)) || !totals || (list_cap > 0 && !lists))
+        return orbm_fail(c0, ORBM_EINVAL, "allpairs: null argument or negative size");
+    totals[0] = totals[1] = 0;
+    if (n_pairs == 0) return ORBM_OK;
+    const int W = std::min(n_ctx, n_pairs);
+    std::vector<int> first(W + 1);
+    for (int c = 0; c <= W; c++) first[c] = (int)((long long)n_pairs * c / W);
+    std::vector<int> rcs(W, ORBM_OK);
+    std::vector<std::vector<uint32_t>> part_lists(W);
+    std::vector<uint32_t> part_tot(2 * (size_t)W, 0);
+    auto work = [&](int c) {
+        const int p0 = first[c], np = first[c + 1] - p0;
+        std::vector<int32_t> fa(np), fb(np);
+        for (int p = 0; p < np; p++) { fa[p] = handles[c][kf_a[p0 + p]]; fb[p] = handles[c][kf_b[p0 + p]]; }
+        std::vector<uint32_t> pid(np);
+        for (int p = 0; p < np; p++) pid[p] = pair_id ? pair_id[p0 + p] : (uint32_t)(p0 + p);     // ids of the WHOLE list
+        part_lists[c].resize(list_cap);
+        rcs[c] = orbm_allpairs_batch(ctxs[c], kind, np, fa.data(), fb.data(), pid.data(), ratio, th, check_ori, stride, threshold,
+                                     summaries + p0, list_cap ? part_lists[c].data() : nullptr, list_cap, &part_tot[2 * (size_t)c], 0);
+    };
+    std::vector<std::thread> workers;
+    for (int c = 1; c < W; c++) workers.emplace_back(work, c);
+    work(0);
+    for (auto &t : workers) t.join();
+    for (int c = 0; c < W; c++)
+        if (rcs[c] < 0) {
+            if (c) orbm_fail(c0, rcs[c], "allpairs: context %d: %s", c, orbm_last_error(ctxs[c]));
+            return rcs[c];
+        }
+    uint64_t entries = 0;
+    for (int c = 0; c < W; c++) {
+        const uint32_t n = part_tot[2 * (size_t)c + 1];
+        const uint32_t have = std::min(n, list_cap);                       // what the slice's buffer holds
+        if (entries < list_cap && have) {
+            const uint32_t take = (uint32_t)std::min<uint64_t>(have, list_cap - entries);
+            memcpy(lists + entries, part_lists[c].data(), (size_t)take * 4);
+        }
+        entries += n;
+        totals[0] += part_tot[2 * (size_t)c];
+    }
+    totals[1] = (uint32_t)std::min<uint64_t>(entries, 0xFFFFFFFFull);     // > list_cap: the lists were cut there, as orbm_allpairs_batch reports it
+    return ORBM_OK;
 }
 
 }  // extern "C"

@@ -9,8 +9,11 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 
 #include "../../include/orbmatch.h"
@@ -30,6 +33,8 @@ const int ORBmatcher::HISTO_LENGTH = 30;  // ORBmatcher.cc:39
 
 namespace {
 std::atomic<int> g_device{-1};
+std::mutex g_devices_mutex;
+std::vector<int> g_devices;        // SetDevices: the GPUs (contexts) a batched SearchByBoW is cut over; empty = one
 }
 
 // ---- one C-ABI context per calling thread (the reference calls the matcher from three threads) -------------
@@ -54,29 +59,39 @@ struct ResEntry {
 };
 struct ThreadCtx {
     orbm_ctx *ctx = nullptr;
+    int device = -1;             // -1: SetDevice / $ORBMATCH_DEVICE / 0
     std::map<ResKey, ResEntry> resident;
     std::list<ResKey> lru[2];    // [0] Frames, [1] KeyFrames; front = most recent
     int hold = 0;                // > 0 while a batched call collects handles: nothing is dropped until it ends
     ~ThreadCtx() { if (ctx) orbm_destroy(ctx); }   // frees every device copy with it
 };
-ThreadCtx &Thread() {
-    static thread_local ThreadCtx t;
-    return t;
+// A calling thread owns one context (and residency table) per GPU it uses: `primary` for everything, `extra[d - 1]` for entry
+// d >= 1 of SetDevices.  A worker thread of a multi-GPU batched call works on one of its PARENT's states (tl_override).
+struct ThreadStates {
+    ThreadCtx primary;
+    std::vector<std::unique_ptr<ThreadCtx>> extra;
+};
+thread_local ThreadCtx *tl_override = nullptr;
+ThreadStates &States() {
+    static thread_local ThreadStates s;
+    return s;
 }
+ThreadCtx &Thread() { return tl_override ? *tl_override : States().primary; }
 std::atomic<size_t> g_limit_kf{16384}, g_limit_frames{8};
 std::atomic<int> g_verify{1};                                    // 0 key only, 1 sampled fingerprint (default), 2 full content hash per call
 std::atomic<const std::atomic<uint64_t> *> g_mp_version{nullptr};
 }  // namespace
-orbm_ctx *NewCtx() {
-    int dev = g_device;
+orbm_ctx *NewCtxOn(int dev) {
+    if (dev < 0) dev = g_device;
     if (dev < 0) { const char *e = getenv("ORBMATCH_DEVICE"); dev = e ? atoi(e) : 0; }
     orbm_ctx *c = orbm_create(dev);
     if (!c) throw runtime_error(string("ORBmatcher: cannot create a GPU context: ") + orbm_last_error(nullptr));
     return c;
 }
+orbm_ctx *NewCtx() { return NewCtxOn(-1); }
 orbm_ctx *HostCtx() {
     ThreadCtx &t = Thread();
-    if (!t.ctx) t.ctx = NewCtx();
+    if (!t.ctx) t.ctx = NewCtxOn(t.device);
     return t.ctx;
 }
 void CheckOn(orbm_ctx *ctx, int rc, const char *what) {
@@ -333,17 +348,32 @@ void ORBmatcher::SetResidentLimits(size_t nKeyFrames, size_t nFrames) { detail::
 void ORBmatcher::SetResidencyVerify(int level) { detail::g_verify = level < 0 ? 0 : level > 2 ? 2 : level; }
 void ORBmatcher::SetMapPointVersion(const std::atomic<uint64_t> *counter) { detail::g_mp_version.store(counter, std::memory_order_release); }
 void ORBmatcher::Prefetch(KeyFrame *pKF) { if (pKF && pKF->N > 0) Resident(pKF, true); }
+namespace {
+template <class Fn>
+void ForEachState(Fn &&fn) {                       // every context of the calling thread
+    detail::ThreadStates &s = detail::States();
+    fn(s.primary);
+    for (auto &e : s.extra) if (e) fn(*e);
+}
+}  // namespace
 void ORBmatcher::Evict(KeyFrame *pKF) {
-    detail::ThreadCtx &t = detail::Thread();
-    if (!pKF || !t.ctx) return;
-    auto it = t.resident.find(KeyOf(true, *pKF));
-    if (it != t.resident.end()) DropResident(t, it);
+    if (!pKF) return;
+    ForEachState([&](detail::ThreadCtx &t) {
+        if (!t.ctx) return;
+        auto it = t.resident.find(KeyOf(true, *pKF));
+        if (it != t.resident.end()) DropResident(t, it);
+    });
 }
 void ORBmatcher::Evict(const Frame &F) {
-    detail::ThreadCtx &t = detail::Thread();
-    if (!t.ctx) return;
-    auto it = t.resident.find(KeyOf(false, F));
-    if (it != t.resident.end()) DropResident(t, it);
+    ForEachState([&](detail::ThreadCtx &t) {
+        if (!t.ctx) return;
+        auto it = t.resident.find(KeyOf(false, F));
+        if (it != t.resident.end()) DropResident(t, it);
+    });
+}
+void ORBmatcher::SetDevices(const std::vector<int> &devices) {
+    std::lock_guard<std::mutex> lock(g_devices_mutex);
+    g_devices = devices;
 }
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
@@ -417,67 +447,99 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
 }
 
 // ---- the candidate loops (Tracking.cc:1778-1801, LoopClosing.cc:433-477) in one launch ---------------------------------
-vector<int> ORBmatcher::SearchByBoW(const vector<KeyFrame *> &vpKFs, Frame &F, vector<vector<MapPoint *>> &vvpMapPointMatches) {
-    const int K = (int)vpKFs.size();
+namespace {
+// Candidates [k0, k1) of a batched SearchByBoW on the CURRENT context (detail::Thread()): variant 0 = (candidate KF, Frame F),
+// variant 1 = (pKF1, candidate KF).  Fills nmatches[k] and out[k] for its candidates only.
+template <class Anchor>
+void BowSlice(int variant, Anchor &anchor, int anchorN, const vector<MapPoint *> *anchorMps, const vector<KeyFrame *> &cands, int k0, int k1,
+              float ratio, bool checkOri, size_t outSize, vector<int> &nmatches, vector<vector<MapPoint *>> &out) {
     HoldResident hold;
-    vector<int> nmatches(K, 0);
-    vvpMapPointMatches.assign(K, vector<MapPoint *>());
     vector<int32_t> ida, idb, which;
-    vector<vector<MapPoint *>> mps(K);
-    const int32_t fid = F.N > 0 ? Resident(F, true) : -1;
-    for (int k = 0; k < K; k++) {
-        KeyFrame *pKF = vpKFs[k];
-        if (!pKF || pKF->isBad()) continue;                                        // Tracking.cc:1781-1782
-        mps[k] = pKF->GetMapPointMatches();
-        vvpMapPointMatches[k] = vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));
-        if (F.N == 0 || pKF->N == 0) continue;
-        ida.push_back(Resident(pKF, mps[k], true)); idb.push_back(fid); which.push_back(k);
+    vector<vector<MapPoint *>> mps(k1 - k0);
+    int32_t anchorId = -1;
+    if (anchorN > 0) {
+        if constexpr (std::is_same<Anchor, Frame>::value) anchorId = Resident(anchor, true);
+        else anchorId = Resident(anchor, *anchorMps, true);
+    }
+    for (int k = k0; k < k1; k++) {
+        KeyFrame *pKF = cands[k];
+        if (!pKF || pKF->isBad()) continue;                                        // Tracking.cc:1781-1782 / LoopClosing.cc:441-445
+        mps[k - k0] = pKF->GetMapPointMatches();
+        out[k] = vector<MapPoint *>(outSize, static_cast<MapPoint *>(NULL));
+        if (anchorN == 0 || pKF->N == 0) continue;
+        const int32_t cid = Resident(pKF, mps[k - k0], true);
+        if (variant == 0) { ida.push_back(cid); idb.push_back(anchorId); }
+        else { ida.push_back(anchorId); idb.push_back(cid); }
+        which.push_back(k);
     }
     const int P = (int)which.size();
-    if (P == 0) return nmatches;
-    vector<int32_t> match((size_t)P * F.N, -1), count(P, 0);
-    Check(orbm_search_bow_batch(Ctx(), 0, P, ida.data(), idb.data(), mfNNratio, mbCheckOrientation ? 1 : 0, F.N, match.data(), count.data(), 0),
+    if (P == 0) return;
+    vector<int32_t> match((size_t)P * anchorN, -1), count(P, 0);
+    Check(orbm_search_bow_batch(Ctx(), variant, P, ida.data(), idb.data(), ratio, checkOri ? 1 : 0, anchorN, match.data(), count.data(), 0),
           "orbm_search_bow_batch");
     for (int p = 0; p < P; p++) {
         const int k = which[p];
-        const int32_t *m = &match[(size_t)p * F.N];
-        for (int i = 0; i < F.N; i++)
-            if (m[i] >= 0) vvpMapPointMatches[k][i] = mps[k][m[i]];
+        const int32_t *m = &match[(size_t)p * anchorN];
+        for (int i = 0; i < anchorN; i++)
+            if (m[i] >= 0) out[k][i] = mps[k - k0][m[i]];
         nmatches[k] = count[p];
     }
+}
+
+// The whole candidate list: on the calling thread's context, or -- after SetDevices({...}) with more than one entry -- cut into
+// contiguous slices, one per listed GPU, each slice on a worker thread with the calling thread's context (and residency table)
+// for that GPU.  Pairs are independent, so the result is the single-context result (LoopClosing.cc:433-477 over shards).
+template <class Anchor>
+void BowBatch(int variant, Anchor &anchor, int anchorN, const vector<MapPoint *> *anchorMps, const vector<KeyFrame *> &cands, float ratio,
+              bool checkOri, size_t outSize, vector<int> &nmatches, vector<vector<MapPoint *>> &out) {
+    const int K = (int)cands.size();
+    vector<int> devs;
+    { std::lock_guard<std::mutex> lock(g_devices_mutex); devs = g_devices; }
+    const int D = std::min((int)devs.size(), K);
+    if (D <= 1 || detail::tl_override) {
+        BowSlice(variant, anchor, anchorN, anchorMps, cands, 0, K, ratio, checkOri, outSize, nmatches, out);
+        return;
+    }
+    detail::ThreadStates &st = detail::States();
+    if (st.primary.device < 0 && !st.primary.ctx) st.primary.device = devs[0];
+    while ((int)st.extra.size() < D - 1) st.extra.emplace_back();
+    vector<detail::ThreadCtx *> state(D);
+    state[0] = &st.primary;
+    for (int d = 1; d < D; d++) {
+        auto &e = st.extra[d - 1];
+        if (!e || (e->device != devs[d])) { e.reset(new detail::ThreadCtx()); e->device = devs[d]; }
+        state[d] = e.get();
+    }
+    vector<std::exception_ptr> err(D);
+    auto run = [&](int d) {
+        try {
+            BowSlice(variant, anchor, anchorN, anchorMps, cands, (int)((long long)K * d / D), (int)((long long)K * (d + 1) / D), ratio, checkOri,
+                     outSize, nmatches, out);
+        } catch (...) { err[d] = std::current_exception(); }
+    };
+    vector<std::thread> workers;
+    for (int d = 1; d < D; d++)
+        workers.emplace_back([&, d] { detail::tl_override = state[d]; run(d); detail::tl_override = nullptr; });
+    run(0);
+    for (auto &w : workers) w.join();
+    for (int d = 0; d < D; d++) if (err[d]) std::rethrow_exception(err[d]);
+}
+}  // namespace
+
+vector<int> ORBmatcher::SearchByBoW(const vector<KeyFrame *> &vpKFs, Frame &F, vector<vector<MapPoint *>> &vvpMapPointMatches) {
+    const int K = (int)vpKFs.size();
+    vector<int> nmatches(K, 0);
+    vvpMapPointMatches.assign(K, vector<MapPoint *>());
+    BowBatch(0, F, F.N, nullptr, vpKFs, mfNNratio, mbCheckOrientation, (size_t)F.N, nmatches, vvpMapPointMatches);
     return nmatches;
 }
 
 vector<int> ORBmatcher::SearchByBoW(KeyFrame *pKF1, const vector<KeyFrame *> &vpKF2s, vector<vector<MapPoint *>> &vvpMatches12) {
     const int K = (int)vpKF2s.size();
-    HoldResident hold;
     vector<int> nmatches(K, 0);
     vvpMatches12.assign(K, vector<MapPoint *>());
     const vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
-    const int N1 = pKF1->N;
-    vector<int32_t> ida, idb, which;
-    vector<vector<MapPoint *>> mps(K);
-    const int32_t id1 = N1 > 0 ? Resident(pKF1, vpMapPoints1, true) : -1;
-    for (int k = 0; k < K; k++) {
-        KeyFrame *pKF2 = vpKF2s[k];
-        if (!pKF2 || pKF2->isBad()) continue;                                      // LoopClosing.cc:441-445
-        mps[k] = pKF2->GetMapPointMatches();
-        vvpMatches12[k] = vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));
-        if (N1 == 0 || pKF2->N == 0) continue;
-        ida.push_back(id1); idb.push_back(Resident(pKF2, mps[k], true)); which.push_back(k);
-    }
-    const int P = (int)which.size();
-    if (P == 0) return nmatches;
-    vector<int32_t> match((size_t)P * N1, -1), count(P, 0);
-    Check(orbm_search_bow_batch(Ctx(), 1, P, ida.data(), idb.data(), mfNNratio, mbCheckOrientation ? 1 : 0, N1, match.data(), count.data(), 0),
-          "orbm_search_bow_batch");
-    for (int p = 0; p < P; p++) {
-        const int k = which[p];
-        const int32_t *m = &match[(size_t)p * N1];
-        for (int i = 0; i < N1; i++)
-            if (m[i] >= 0) vvpMatches12[k][i] = mps[k][m[i]];
-        nmatches[k] = count[p];
-    }
+    BowBatch(1, pKF1, pKF1->N, &vpMapPoints1, vpKF2s, mfNNratio, mbCheckOrientation, vpMapPoints1.size(), nmatches, vvpMatches12);
     return nmatches;
 }
 

@@ -79,6 +79,13 @@ public:
     // ---- extensions (not in the reference) -----------------------------------------------------------------------
     // GPU the searches run on (contexts created after the call); default 0 or $ORBMATCH_DEVICE.
     static void SetDevice(int device);
+    // Several GPUs behind the batched SearchByBoW overloads below (the reference's candidate loops LoopClosing.cc:433-477 /
+    // Tracking.cc:1778-1801 over shards): the candidate list is cut into one contiguous slice per listed device, every slice
+    // runs on a worker thread with the calling thread's own context and residency table for that device, and the results
+    // are put together on the host -- pairs are independent, no collective is involved.  The same device may be listed
+    // more than once (two contexts on one GPU).  Call it before the calling thread's first search; an empty list or a list
+    // of one restores the single-context behaviour.
+    static void SetDevices(const std::vector<int> &devices);
 
     // Device residency.  Every Frame / KeyFrame a thread searches is uploaded ONCE into that thread's context
     // (descriptors, keypoints, FeatureVector; the grid is built on the device) and found again by

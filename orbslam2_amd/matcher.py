@@ -273,6 +273,26 @@ class Context:
                                               threshold, _addr(summ), _addr(lists) if list_cap else None, list_cap, _addr(totals), 0))
         return summ[:p], lists[: min(int(totals[1]), list_cap)], totals
 
+    @staticmethod
+    def allpairs_multi(ctxs, handles, kind: int, kf_a, kf_b, pair_id, ratio: float, th: int, check_ori: bool, stride: int,
+                       threshold: int, list_cap: int):
+        """orbm_allpairs: one pair list over several contexts (GPUs) from this process; handles[c][k] = handle of keyframe k
+        in ctxs[c].  Returns what allpairs_batch returns for the whole list."""
+        import ctypes as C
+        L = ctxs[0]._L
+        n_ctx = len(ctxs)
+        carr = (C.c_void_p * n_ctx)(*[c._h for c in ctxs])
+        hs = [np.ascontiguousarray(h, np.int32) for h in handles]
+        harr = (C.c_void_p * n_ctx)(*[h.ctypes.data for h in hs])
+        kf_a = np.ascontiguousarray(kf_a, np.int32); kf_b = np.ascontiguousarray(kf_b, np.int32)
+        p = len(kf_a)
+        pid = None if pair_id is None else np.ascontiguousarray(pair_id, np.uint32)
+        summ = np.zeros(max(p, 1), Context.SUMMARY_DTYPE); lists = np.zeros(max(list_cap, 1), np.uint32); totals = np.zeros(2, np.uint32)
+        rc = L.orbm_allpairs(carr, n_ctx, harr, kind, p, _addr(kf_a), _addr(kf_b), _addr(pid), ratio, th, int(check_ori), stride,
+                             threshold, _addr(summ), _addr(lists) if list_cap else None, list_cap, _addr(totals))
+        ctxs[0]._chk(rc)
+        return summ[:p], lists[: min(int(totals[1]), list_cap)], totals
+
     def allpairs_batch_dev(self, kind, n_pairs, fa_ptr, fb_ptr, pair_id_ptr, ratio, th, check_ori, stride, threshold,
                            summaries_ptr, lists_ptr, list_cap, totals_ptr):
         self._chk(self._L.orbm_allpairs_batch(self._h, kind, n_pairs, fa_ptr, fb_ptr, pair_id_ptr, ratio, th, int(check_ori), stride,

@@ -367,6 +367,24 @@ static void TestResidency() {
             bad += c != n2[k] || one != all[k]; tot += c;
         }
         EXPECT(bad == 0 && tot > 50, "batched SearchByBoW(KF, KFs): %d candidates differ from the single calls (%d matches in all)", bad, tot);
+        // several contexts behind the same calls (SetDevices; here three contexts on the one GPU): the candidate list is cut into
+        // slices, each on its own context and worker thread -- same result as the single context (LoopClosing.cc:433-477 over shards)
+        {
+            vector<vector<MapPoint *>> one_kf, one_f, multi;
+            const vector<int> w_kf = matcher.SearchByBoW(&A, cand, one_kf);
+            const vector<int> w_f = matcher.SearchByBoW(cand, F, one_f);
+            ORBmatcher::SetDevices({0, 0, 0});
+            for (int rep = 0; rep < 2; rep++) {                      // second round: every slice's keyframes are resident in its context
+                const vector<int> g_kf = matcher.SearchByBoW(&A, cand, multi);
+                EXPECT(g_kf == w_kf && multi == one_kf, "SearchByBoW(KF, KFs) over three contexts differs from one context (round %d)", rep);
+                const vector<int> g_f = matcher.SearchByBoW(cand, F, multi);
+                EXPECT(g_f == w_f && multi == one_f, "SearchByBoW(KFs, F) over three contexts differs from one context (round %d)", rep);
+            }
+            double tm = NowMs();
+            for (int r = 0; r < 20; r++) matcher.SearchByBoW(cand, F, multi);
+            printf("latency SearchByBoW(%d candidate KFs, F) over three contexts on one GPU: %.3f ms per call\n", K, (NowMs() - tm) / 20);
+            ORBmatcher::SetDevices({});
+        }
         double t0 = NowMs();
         { vector<vector<MapPoint *>> tmp; for (int r = 0; r < 20; r++) matcher.SearchByBoW(cand, F, tmp); }
         printf("latency SearchByBoW(%d candidate KFs, F) batched, resident: %.3f ms per call\n", K, (NowMs() - t0) / 20);

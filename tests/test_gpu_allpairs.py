@@ -67,3 +67,35 @@ def test_allpairs_batch_against_the_oracle(ctx, orc, kind):
     with pytest.raises(OrbmError):
         ctx.allpairs_batch(kind, ids[a], ids[b], pid, 0.75, 50, True, 100, threshold, list_cap=10)   # stride below a frame's n
     ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("kind,n_ctx", [(0, 2), (1, 3), (2, 2)])
+def test_allpairs_over_several_contexts_equals_one_context(ctx, kind, n_ctx):
+    """orbm_allpairs: the pair list cut over several contexts -- here all on the test box's one GPU, each with
+    its own replica of the store, handles differing between contexts -- returns exactly the records one context returns."""
+    from orbslam2_amd.matcher import Context
+    n, n_kf = 600, 11
+    kfs = synth.keyframe_pool(seed=synth.SEED0 + 70 + kind, n_kf=n_kf, n=n, window=1000, mp_valid_frac=0.9)
+    ids = ctx.upload_frames(kfs)
+    a, b = allpairs.shard_pairs(n_kf, 0, 1, tile=4)
+    pid = allpairs.pair_ids(a, b, n_kf)
+    want = ctx.allpairs_batch(kind, ids[a], ids[b], pid, 0.75, 50, True, n, 20, list_cap=len(a) * n)
+    others = [Context(0) for _ in range(n_ctx - 1)]
+    try:
+        handles = [ids]
+        for k, c in enumerate(others):
+            c.upload_frames(kfs[: k + 1])                       # shift the handle numbering of this context
+            handles.append(c.upload_frames(kfs))
+        got = Context.allpairs_multi([ctx] + others, handles, kind, a, b, pid, 0.75, 50, True, n, 20, list_cap=len(a) * n)
+        assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64))
+        assert np.array_equal(got[1], want[1]) and tuple(got[2]) == tuple(want[2]) and want[2][0] > 0
+        # a short list buffer: cut at list_cap, totals still say how many there were
+        cap = int(want[2][1]) // 2
+        cut = Context.allpairs_multi([ctx] + others, handles, kind, a, b, pid, 0.75, 50, True, n, 20, list_cap=cap)
+        assert tuple(cut[2]) == tuple(want[2]) and np.array_equal(cut[1], want[1][:cap])
+        with pytest.raises(OrbmError):
+            Context.allpairs_multi([ctx] + others, handles, 7, a, b, pid, 0.75, 50, True, n, 20, list_cap=16)
+    finally:
+        for c in others:
+            c.close()
+    ctx.free_frames(ids)
