@@ -361,6 +361,17 @@ int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t 
 int orbm_search_window_free_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset, int dist_th,
                                   int chi2_gate, int32_t stride_q, int32_t *best_idx, int io_on_device);
 
+/* ---- a6 / a11 as ONE call per search: what a tracking thread issues per frame (Tracking.cc:1152, 1549-1560, 1865 -- one
+ * fresh query set into one resident frame).  The query arrays travel with the call (one pinned host->device copy together
+ * with the id lists, nothing is allocated or freed, one stream synchronisation); results equal orbm_*_queries_upload +
+ * orbm_search_proj_points_batch / orbm_search_window_batch with n_inst = 1 + orbm_queries_free.  frame: a handle of
+ * orbm_frames_upload; slot_flags: NULL or n bytes (n = the frame's keypoints) replacing its mp_flags for this search;
+ * owner: n ints out; count: nmatches out.  All pointers are HOST memory. */
+int orbm_search_proj_points_once(orbm_ctx *ctx, int32_t frame, const orbm_proj_queries *queries, float th, float ratio,
+                                 const uint8_t *slot_flags, int32_t *owner, int32_t *count);
+int orbm_search_window_once(orbm_ctx *ctx, int mode, int32_t frame, const orbm_win_queries *queries, int dist_th, int check_ori,
+                            const uint8_t *slot_flags, int32_t *owner, int32_t *count);
+
 /* ---- a5: SearchForInitialization (ORBmatcher.cc:562-689) --------------------------------------
  * prev_xy: n1 x 2 floats, vbPrevMatched, in/out (:684-686); matches12: n1 ints, -1 = none.
  * Host pointers.  Returns nmatches. */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "orbm_vocab_upload", "orbm_vocab_free", "orbm_frames_compute_bow", "orbm_vocab_transform", "orbm_frame_fv_download",
     "orbm_bowvecs_upload", "orbm_bowvecs_free", "orbm_bow_score_batch", "orbm_bowvec_download",
     "orbm_popcount_peak", "orbm_search_bow_batch_noalloc",
-    "orbm_bf2nn_prepare", "orbm_pack_records", "orbm_allpairs_batch", "orbm_allpairs_shard", "orbm_allpairs",
+    "orbm_bf2nn_prepare", "orbm_pack_records", "orbm_allpairs_batch", "orbm_allpairs_shard", "orbm_allpairs", "orbm_search_proj_points_once", "orbm_search_window_once",
 ]
 
 _lib = None
@@ -64,6 +64,8 @@ def load():
     L.orbm_pack_records.argtypes = [vp, C.c_int, vp, vp, vp, i32, C.c_int, vp, vp, C.c_uint32, vp, C.c_int]
     L.orbm_allpairs_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, i32, C.c_int, vp, vp, C.c_uint32, vp, C.c_int]
     L.orbm_allpairs.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, f32, C.c_int, C.c_int, i32, C.c_int, vp, vp, C.c_uint32, vp]
+    L.orbm_search_proj_points_once.argtypes = [vp, i32, C.POINTER(CProjQueries), f32, f32, vp, vp, vp]
+    L.orbm_search_window_once.argtypes = [vp, C.c_int, i32, C.POINTER(CWinQueries), C.c_int, C.c_int, vp, vp, vp]
     L.orbm_allpairs_shard.restype = C.c_int64
     L.orbm_allpairs_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
     L.orbm_search_triang_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, i32, vp, vp, C.c_int]

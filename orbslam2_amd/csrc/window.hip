@@ -30,6 +30,7 @@
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 #include "orbm_internal.h"
 
 namespace {
@@ -2047,6 +2048,96 @@ extern "C" int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, con
     if (ctx && (mode < 0 || mode > 2)) return orbm_fail(ctx, ORBM_EINVAL, "search_window_batch: mode must be 0, 1 or 2");
     return run_window_batch(ctx, mode, n_inst, frame, qset, 1.0f, 1.0f, dist_th, check_ori, slot_flags, stride, owner,
                             counts, io_on_device, "search_window_batch");
+}
+
+// ---- one call = one search: the query set travels WITH the call.  What a tracking thread issues per frame
+// (Tracking.cc:1152, 1549-1560, 1865) is one search of one fresh query set into one resident frame; through
+// orbm_*_queries_upload + orbm_search_*_batch + orbm_queries_free that is three calls, three stream synchronisations, an
+// arena and two table updates.  Here the query arrays, a one-entry query-set table and the id lists are packed into the
+// context's pinned staging block and go to the device as ONE copy, the kernels read the set where it landed, and outputs
+// come back as one copy: a single synchronisation, nothing allocated, nothing to free.  Results are those of the batch
+// entry points with n_inst = 1.
+static int search_once(orbm_ctx *ctx, int mode, int32_t frame, const orbm_proj_queries *pq, const orbm_win_queries *wq, float th, float ratio,
+                       int dist_th, int check_ori, const uint8_t *slot_flags, int32_t *owner, int32_t *count, const char *who) {
+    if (!ctx) return ORBM_EINVAL;
+    if ((!pq && !wq) || !owner || !count) return orbm_fail(ctx, ORBM_EINVAL, "%s: null argument", who);
+    int rc = orbm_check_frames(ctx, 1, &frame, "frame");
+    if (rc) return rc;
+    const int nq = pq ? pq->n : wq->n;
+    const int nF = ctx->h_frames[frame].n;
+    if (nq < 0) return orbm_fail(ctx, ORBM_EINVAL, "%s: n < 0", who);
+    if (nF > WIN_MAX_N) return orbm_fail(ctx, ORBM_ELIMIT, "%s: frames of more than %d keypoints are not supported by the windowed kernels (got %d)", who, WIN_MAX_N, nF);
+    if (pq && nq > 0 && (!pq->desc || !pq->proj_x || !pq->proj_y || !pq->proj_xr || !pq->level || !pq->view_cos))
+        return orbm_fail(ctx, ORBM_EINVAL, "%s: null query array", who);
+    if (wq && nq > 0 && (!wq->desc || !wq->u || !wq->v || !wq->radius || !wq->min_level || !wq->max_level))
+        return orbm_fail(ctx, ORBM_EINVAL, "%s: null query array", who);
+    *count = 0;
+    if (nF == 0) return ORBM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)nq;
+    rc = orbm_ws_reserve(ctx, n * 64 + 16 * 256 + (size_t)nF * 5 + 8192);
+    if (rc) return rc;
+    IoStage io(ctx, 0);
+    QSetDev qs;
+    memset(&qs, 0, sizeof qs);
+    qs.n = nq; qs.kind = pq ? 0 : 1;
+    const void *d;
+    std::vector<uint32_t> packed;
+    std::vector<uint8_t> fl;
+    if (pq) {
+        for (size_t i = 0; i < n; i++)
+            if (pq->level[i] < 0 || pq->level[i] >= ORBM_MAX_LEVELS) return orbm_fail(ctx, ORBM_EINVAL, "%s: level[%zu] out of range", who, i);
+        packed.resize(4 * n + 4);
+        for (size_t i = 0; i < n; i++) {
+            memcpy(&packed[4 * i], &pq->proj_x[i], 4); memcpy(&packed[4 * i + 1], &pq->proj_y[i], 4); memcpy(&packed[4 * i + 2], &pq->proj_xr[i], 4);
+            const uint32_t f = pq->flags ? pq->flags[i] : (uint32_t)(ORBM_Q_VALID | ORBM_Q_OBS);
+            packed[4 * i + 3] = (uint32_t)pq->level[i] | (f << 8) | (pq->view_cos[i] >= 0.998f ? 1u << 16 : 0u);   // ORBmatcher.cc:168-174
+        }
+        if ((rc = io.in(n ? pq->desc : (const uint8_t *)packed.data(), std::max<size_t>(n * 32, 16), &d))) return rc;
+        qs.desc = (const uint32_t *)d;
+        if ((rc = io.in(packed.data(), std::max<size_t>(n * 16, 16), &d))) return rc;
+        qs.pk = (const uint32_t *)d;
+    } else {
+        static const uint8_t zero16[16] = {0};
+        auto put = [&](const void *p, size_t bytes, const void **out) { return io.in(n ? p : (const void *)zero16, std::max<size_t>(bytes, 16), out); };
+        if ((rc = put(wq->desc, n * 32, &d))) return rc; qs.desc = (const uint32_t *)d;
+        if ((rc = put(wq->u, n * 4, &d))) return rc; qs.f0 = (const float *)d;
+        if ((rc = put(wq->v, n * 4, &d))) return rc; qs.f1 = (const float *)d;
+        if ((rc = put(wq->radius, n * 4, &d))) return rc; qs.f2 = (const float *)d;
+        if (wq->ur) { if ((rc = put(wq->ur, n * 4, &d))) return rc; qs.f3 = (const float *)d; }
+        if (wq->angle) { if ((rc = put(wq->angle, n * 4, &d))) return rc; qs.angle = (const float *)d; }
+        if ((rc = put(wq->min_level, n * 4, &d))) return rc; qs.l0 = (const int32_t *)d;
+        if ((rc = put(wq->max_level, n * 4, &d))) return rc; qs.l1 = (const int32_t *)d;
+        if (wq->flags) { if ((rc = put(wq->flags, n, &d))) return rc; }
+        else { fl.assign(std::max<size_t>(n, 16), ORBM_Q_VALID | ORBM_Q_OBS); if ((rc = io.in(fl.data(), fl.size(), &d))) return rc; }
+        qs.flags = (const uint8_t *)d;
+    }
+    const void *dtab, *dids, *dsf = nullptr; void *down, *dc;
+    const int32_t ids[4] = {frame, 0, 0, 0};              // frame_ids[0] = frame, qset_ids[0] = 0 (the one-entry table below)
+    if ((rc = io.in(&qs, sizeof qs, &dtab)) || (rc = io.in(ids, sizeof ids, &dids)) || (rc = io.in(slot_flags, (size_t)nF, &dsf)) ||
+        (rc = io.out(owner, (size_t)nF * 4, &down)) || (rc = io.out(count, 4, &dc)))
+        return rc;
+    WinParams P;
+    memset(&P, 0, sizeof P);
+    P.frames = ctx->d_frames; P.qsets = (const QSetDev *)dtab;
+    P.frame_ids = (const int32_t *)dids; P.qset_ids = (const int32_t *)dids + 1;
+    P.slot_flags = (const uint8_t *)dsf;
+    P.out = (int32_t *)down; P.counts = (int32_t *)dc;
+    P.th = th; P.ratio = ratio; P.dist_th = dist_th; P.check_ori = check_ori; P.stride = nF;
+    rc = launch_window(ctx, mode, P, 1, std::max(nF, 1), nq, ctx->h_frames[frame].n_levels);
+    if (rc) return rc;
+    return io.finish();
+}
+
+extern "C" int orbm_search_proj_points_once(orbm_ctx *ctx, int32_t frame, const orbm_proj_queries *queries, float th, float ratio,
+                                            const uint8_t *slot_flags, int32_t *owner, int32_t *count) {
+    return search_once(ctx, MODE_PROJ, frame, queries, nullptr, th, ratio, ORBM_TH_HIGH, 0, slot_flags, owner, count, "search_proj_points_once");
+}
+
+extern "C" int orbm_search_window_once(orbm_ctx *ctx, int mode, int32_t frame, const orbm_win_queries *queries, int dist_th, int check_ori,
+                                       const uint8_t *slot_flags, int32_t *owner, int32_t *count) {
+    if (ctx && (mode < 0 || mode > 2)) return orbm_fail(ctx, ORBM_EINVAL, "search_window_once: mode must be 0, 1 or 2");
+    return search_once(ctx, mode, frame, nullptr, queries, 1.0f, 1.0f, dist_th, check_ori, slot_flags, owner, count, "search_window_once");
 }
 
 extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, float *prev_xy, int window, float ratio,

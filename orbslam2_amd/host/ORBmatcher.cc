@@ -300,13 +300,11 @@ struct WinQ {
     int Run(int mode, int32_t frame_id, int n_slots, int dist_th, bool check_ori, bool with_ur, bool with_angle,
             const uint8_t *slot_flags, vector<int32_t> &owner) {
         orbm_win_queries q = View(with_ur, with_angle);
-        int32_t qid = -1, count = 0;
-        Check(orbm_win_queries_upload(Ctx(), 1, &q, &qid), "orbm_win_queries_upload");
+        int32_t count = 0;
         owner.assign(max(n_slots, 1), -1);
-        int rc = orbm_search_window_batch(Ctx(), mode, 1, &frame_id, &qid, dist_th, check_ori ? 1 : 0, slot_flags, n_slots,
-                                          owner.data(), &count, 0);
-        orbm_queries_free(Ctx(), 1, &qid);
-        Check(rc, "orbm_search_window_batch");
+        // one call: the query arrays travel with the search (one pinned copy in, one out, one synchronisation)
+        Check(orbm_search_window_once(Ctx(), mode, frame_id, &q, dist_th, check_ori ? 1 : 0, slot_flags, owner.data(), &count),
+              "orbm_search_window_once");
         return count;
     }
 };
@@ -404,12 +402,9 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoin
     orbm_proj_queries q;
     q.n = Q; q.desc = desc.data(); q.proj_x = px.data(); q.proj_y = py.data(); q.proj_xr = pxr.data();
     q.level = lvl.data(); q.view_cos = vc.data(); q.flags = flags.data();
-    int32_t qid = -1, count = 0;
-    Check(orbm_proj_queries_upload(Ctx(), 1, &q, &qid), "orbm_proj_queries_upload");
+    int32_t count = 0;
     vector<int32_t> owner(F.N, -1);
-    int rc = orbm_search_proj_points_batch(Ctx(), 1, &fid, &qid, th, mfNNratio, nullptr, F.N, owner.data(), &count, 0);
-    orbm_queries_free(Ctx(), 1, &qid);
-    Check(rc, "orbm_search_proj_points_batch");
+    Check(orbm_search_proj_points_once(Ctx(), fid, &q, th, mfNNratio, nullptr, owner.data(), &count), "orbm_search_proj_points_once");
     for (int idx = 0; idx < F.N; idx++)
         if (owner[idx] >= 0) F.mvpMapPoints[idx] = vpMapPoints[owner[idx]];   // :160
     return count;

@@ -347,6 +347,24 @@ class Context:
                                                         stride, _addr(owner), _addr(counts), 0))
         return counts[:k], owner[:k]
 
+    def search_proj_points_once(self, frame: int, queries: ProjQueries, th: float, ratio: float, n: int, slot_flags=None):
+        """One search, the query set travelling with the call (orbm_search_proj_points_once): -> (count, owner[n])"""
+        import ctypes as C
+        v = queries.view()
+        owner = np.full(max(n, 1), -1, np.int32); cnt = np.zeros(1, np.int32)
+        sf = None if slot_flags is None else np.ascontiguousarray(slot_flags, np.uint8)
+        self._chk(self._L.orbm_search_proj_points_once(self._h, int(frame), C.byref(v), th, ratio, _addr(sf), _addr(owner), _addr(cnt)))
+        return int(cnt[0]), owner[:n]
+
+    def search_window_once(self, mode: int, frame: int, queries: WinQueries, dist_th: int, check_ori: bool, n: int, slot_flags=None):
+        """orbm_search_window_once: -> (count, owner[n])"""
+        import ctypes as C
+        v = queries.view()
+        owner = np.full(max(n, 1), -1, np.int32); cnt = np.zeros(1, np.int32)
+        sf = None if slot_flags is None else np.ascontiguousarray(slot_flags, np.uint8)
+        self._chk(self._L.orbm_search_window_once(self._h, mode, int(frame), C.byref(v), dist_th, int(check_ori), _addr(sf), _addr(owner), _addr(cnt)))
+        return int(cnt[0]), owner[:n]
+
     def search_proj_points_dev(self, n_inst, frame_ptr, qset_ptr, th, ratio, slot_flags_ptr, stride, owner_ptr,
                                counts_ptr):
         self._chk(self._L.orbm_search_proj_points_batch(self._h, n_inst, frame_ptr, qset_ptr, th, ratio,

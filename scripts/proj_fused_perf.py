@@ -14,6 +14,13 @@ NQ = int(os.environ.get("ORBM_NQ", "50000"))       # queries per instance (prefi
 ctx = Context(0)
 L = _lib.load()
 f, q = synth.proj_instance(seed=synth.SEED0 + 3, n=2000, n_queries=50000)
+OBS = float(os.environ.get("ORBM_OBS_FRAC", "1.0"))      # < 1: only this share of the frame's keypoints is ever observed by a query
+if OBS < 1.0:                                             # (the other slots stay free for the whole search: no exhaustion)
+    g = np.random.default_rng(123)
+    src = g.integers(0, int(2000 * OBS), 50000)
+    q.desc[:] = synth.observe(g, f.desc[src], 0.08)
+    q.proj_x[:] = (f.x[src] + g.normal(0, 2.0, 50000)).astype(np.float32); q.proj_y[:] = (f.y[src] + g.normal(0, 2.0, 50000)).astype(np.float32)
+    q.level[:] = np.clip(f.octave[src] + (g.random(50000) < 0.3), 0, 7).astype(np.int32)
 rng = np.random.default_rng(0)
 sets = []
 for k in range(n_sets):

@@ -979,3 +979,34 @@ def test_relocalisation_chain_stays_on_the_device(ctx, orc):
     finally:
         ctx.free_vocabulary(vid)
         ctx.free_frames(ids)
+
+
+def test_one_call_searches_equal_the_batch_entry_points(ctx, orc):
+    """orbm_search_proj_points_once / orbm_search_window_once (the query set travels with the call: one copy in, one out, one
+    synchronisation) against the oracle, with and without slot flags, empty query sets and one-keypoint frames included."""
+    rng = np.random.default_rng(77)
+    for seed, n, nq, th, stereo in ((31, 2000, 1500, 3.0, False), (32, 700, 4000, 5.0, True), (33, 1, 10, 3.0, False), (34, 900, 0, 3.0, False),
+                                    (35, 1500, 20000, 1.0, False)):
+        f, q = synth.proj_instance(seed=seed, n=n, n_queries=nq, claimed_frac=0.1, obs_frac=0.7, stereo=stereo)
+        fid = ctx.upload_frames([f])
+        for use_slots in (False, True):
+            sf = None
+            if use_slots:
+                sf = np.zeros(n, np.uint8); sf[rng.random(n) < 0.3] = MP_PRESENT | MP_OBS; sf[rng.random(n) < 0.1] = MP_PRESENT
+            cnt, owner = ctx.search_proj_points_once(fid[0], q, th, 0.8, n, slot_flags=sf)
+            wc, wo, _ = orc.search_proj_points(f, q, th, 0.8, slot_flags=sf)
+            assert cnt == wc and np.array_equal(owner, wo), (seed, use_slots)
+        ctx.free_frames(fid)
+    for mode in (0, 1, 2):
+        for wth, nq in ((7.0, 1500), (15.0, 1200), (7.0, 0)):
+            f, q = synth.window_instance(990 + mode, mode, n=1500, n_queries=max(nq, 1), stereo=(mode == 0), th=wth)
+            if nq == 0:
+                from orbslam2_amd.views import WinQueries
+                q = WinQueries(desc=q.desc[:0], u=q.u[:0], v=q.v[:0], radius=q.radius[:0], min_level=q.min_level[:0], max_level=q.max_level[:0],
+                               ur=None if q.ur is None else q.ur[:0], angle=None if q.angle is None else q.angle[:0], flags=q.flags[:0])
+            fid = ctx.upload_frames([f])
+            dth = 100 if mode < 2 else 50
+            cnt, owner = ctx.search_window_once(mode, fid[0], q, dth, mode < 2, 1500)
+            wc, wo, _ = orc.search_window(mode, f, q, dth, mode < 2)
+            assert cnt == wc and np.array_equal(owner, wo), (mode, wth, nq)
+            ctx.free_frames(fid)
