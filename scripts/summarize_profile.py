@@ -72,15 +72,39 @@ try:
                 vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
         return sorted(vals.values())
     win = {}
-    for kern in ("collect_kernel", "window_kernel"):
+    for kern in ("fused_kernel", "collect_kernel", "window_kernel"):
         fs = per_launch("fetch", kern, "FETCH_SIZE"); ws = per_launch("write", kern, "WRITE_SIZE")
+        if not fs or not ws:
+            continue
         kr = [r for r in rows if kern in r["Name"]][0]
         # the batch launches are the large ones: take the maximum over dispatches
         win[kern] = {"name": kr["Name"][:70], "calls": int(kr["Calls"]), "max_ns": float(kr["MaxNs"]), "min_ns": float(kr["MinNs"]),
                      "FETCH_SIZE_KiB_raw_batch": fs[-1], "WRITE_SIZE_KiB_raw_batch": ws[-1],
                      "hbm_bytes_batch_launch": (2 * fs[-1] + ws[-1]) * 1024}
     win["algorithmic_bytes_batch_launch"] = 256 * (50000 * 53 + 2000 * 49 + 3073 * 4 + 2000 * 4)
-    win["note"] = "batch = 256 instances x 50k queries, th=3, 64 distinct query sets; max_ns = the batch launch, min_ns = one instance alone"
+    win["note"] = ("batch = 256 instances x 50k queries, 256 distinct query sets, launches at th = 3, 1 and 5 (fused_kernel: one launch per batch; "
+                   "max over dispatches = the th 5 launch for time, counters are of the largest dispatch); collect_kernel + window_kernel = one instance alone (split form)")
+    try:
+        fsq = {}
+        for sub in ("sq", "sq2"):
+            f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
+            per = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in _csv.DictReader(open(f)):
+                if "fused_kernel" in r["Kernel_Name"]:
+                    per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            # the batch launches, in issue order: th 3 (4 repetitions), then th 1 and th 5 (bench.py secondary()); mean over the th 3 ones
+            disp = sorted(per.items(), key=lambda kv: int(kv[0]))
+            big = [v for k, v in disp if v.get("SQ_WAVES", v.get("SQ_BUSY_CYCLES", 0)) > 0]
+            if big:
+                first = big[: min(4, len(big))]
+                for cname in first[0]:
+                    fsq[cname] = sum(d.get(cname, 0.0) for d in first) / len(first)
+        win["fused_kernel_counters_mean_of_first_launches"] = fsq
+        if "SQ_INSTS_VALU" in fsq:
+            groups = 256 * 50000 / 64.0
+            win["fused_kernel_per_64_queries"] = {k: fsq[k] / groups for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if k in fsq}
+    except Exception as e:
+        win["fused_counters_error"] = repr(e)
     summ["windowed_search"] = win
     # SearchByBoW: the matrix-core form (bowm_kernel; the one-workgroup-per-pair launches are the 8192-pair measurement of
     # `extra.search_bow_kfkf_*` and the 16384-pair launches of the config-5 triangle)
@@ -99,6 +123,19 @@ try:
         summ["bowm_counters_error"] = repr(e)
 except Exception as e:
     summ["secondary_error"] = repr(e)
-json.dump({"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_summary.json"}, open(f"profiles/{tag}_bf2nn_traffic.json", "w"))
+traffic = {"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_bench_summary.json", "store_keyframes": 640, "pairs_per_launch": 16384}
+try:
+    ff, _ = counters("fetch_full"); wf, _ = counters("write_full")
+    hbm_full = (2 * ff["FETCH_SIZE"] + wf["WRITE_SIZE"]) * 1024
+    summ["hbm_bytes_per_launch_4500_keyframe_store"] = hbm_full
+    summ["FETCH_SIZE_KiB_raw_4500"] = ff["FETCH_SIZE"]; summ["WRITE_SIZE_KiB_raw_4500"] = wf["WRITE_SIZE"]
+    traffic = {"hbm_bytes_per_launch": hbm_full, "source": f"profiles/{tag}_bench_summary.json", "store_keyframes": 4500, "pairs_per_launch": 16384,
+               "FETCH_SIZE_KiB_raw": ff["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": wf["WRITE_SIZE"],
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of `bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline` (the "
+                       "4500-keyframe store bench.py times), mean over the bf2nn_mfma4r_kernel launches; KiB -> bytes, FETCH_SIZE doubled (gfx950 counts "
+                       "half the bytes of 16-byte-per-lane reads: MI355X_MICROARCH.md)"}
+except Exception as e:
+    summ["traffic_full_store_error"] = repr(e)
+json.dump(traffic, open(f"profiles/{tag}_bf2nn_traffic.json", "w"))
 json.dump(summ, open(f"profiles/{tag}_bench_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
