@@ -525,14 +525,13 @@ constexpr int FUSED_CHUNK = FUSED_THREADS - 64;   // queries per chunk: waves 1.
 constexpr int PEND_WORDS = 10;                    // pending entry: meta, the query's angle, eight candidate words
 constexpr int FPARK = 2;                          // survivors a lane parks (in registers) between two distance passes
 
-static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask, bool desc_lds) {
+static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask) {
     const int total = c.base[c.nstruct];
     const size_t offn = (size_t)((total + 6) & ~1);
     const size_t n4 = (size_t)((c.n_cap + 3) & ~3);
     return (((offn / 2 + 3) & ~(size_t)3)) * 4 + n4 * 16 + (size_t)((c.rec_cap + 7) & ~7) * 2 + (size_t)((c.n_cap + 7) & ~7) * 2 +
            n4 * 4 * (3 + (with_binmask ? 1 : 0)) + (size_t)64 * PEND_WORDS * 4 +
-           (size_t)(((c.rec_cap + 31) / 32 + 4) & ~3) * 4 /* fbits */ + (8 * 12 + 8 * 96) * 4 /* fblk, fcnt */ + 64 +
-           (desc_lds ? (size_t)c.n_cap * 32 + 16 : 0);
+           (size_t)(((c.rec_cap + 31) / 32 + 4) & ~3) * 4 /* fbits */ + (8 * 12 + 8 * 96) * 4 /* fblk, fcnt */ + 64;
 }
 
 // raw per-query parameters as loaded (requested a chunk ahead), decoded when the chunk is searched
@@ -611,7 +610,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, CoarseCfg cfg, uint32_t *tail_scratch, int tcap, int32_t *redo_flags, int desc_lds,
+__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, CoarseCfg cfg, uint32_t *tail_scratch, int tcap, int32_t *redo_flags,
                                                                 unsigned long long *trace) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
@@ -651,7 +650,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
     // (two 16-bit counters per word).  A query whose window touches no such block is finished without a walk.
     uint32_t *fblk = fbits + fwords;
     uint32_t *fcnt = fblk + 8 * 12;
-    v4u *l_desc = reinterpret_cast<v4u *>(fcnt + 8 * 96 + 4);                     // desc_lds: the frame's descriptors by stream position
     int *hist = s_hist, *nmatch = s_hist + 32, *keep = s_hist + 33;
 #ifdef ORBM_DIAG
     if (trace && inst == 0 && tid == 0) trace[0] = wall_clock64();
@@ -715,10 +713,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
         const int kp = (int)(w & 0xFFFFu);
         c_rec[j] = v4f{rc.x, rc.y, rc.z, __uint_as_float((uint32_t)j | ((uint32_t)oct << 13) | ((uint32_t)cx << 17) | ((uint32_t)cy << 23))};
         l_kp[j] = (uint16_t)kp;
-        if (desc_lds) {
-            const gptr<const v4u> gd = (gptr<const v4u>)F.desc;
-            l_desc[2 * j] = gd[2 * kp]; l_desc[2 * j + 1] = gd[2 * kp + 1];
-        }
         // slot state, by stream position
         uint32_t s0;
         if (MODE == MODE_INIT) s0 = (uint32_t)INT_MAX;                                   // vMatchedDistance (:573)
@@ -852,8 +846,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                                 if (4 * g + u < ncand2 && consider(cc[4 * g + u], stv[u])) freem |= 1u << (4 * g + u);
                         }
                     }
-                    for (int i = WIN_CACHE; i < wave_ncand; i++)
-                        if (i < ncand2) { const uint32_t v = mytail[i - NW]; consider(v, state[word_slot(v)]); }
+                    // candidates beyond the registers (very wide windows): four words per load from the query's tail
+                    for (int i = WIN_CACHE; i < wave_ncand; i += 4)
+                        if (i < ncand2) {
+                            const v4u t4 = *(gptr<const v4u>)(mytail + (i - NW));
+                            const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+                            uint32_t stv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) stv[u] = i + u < ncand2 ? state[word_slot(tw[u])] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) if (i + u < ncand2) consider(tw[u], stv[u]);
+                        }
                 }
             }
             const int none = MODE == MODE_INIT ? INT_MAX : 256;
@@ -886,11 +889,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
 #pragma unroll
                         for (int i = 0; i < WIN_CACHE; i++)
                             if ((freem >> i) & 1u) atomicMax(&post[word_slot(cc[i])], mypost);
-                        for (int i = WIN_CACHE; i < wave_ncand; i++)
+                        for (int i = WIN_CACHE; i < wave_ncand; i += 4)
                             if (i < ncand2) {
-                                const uint32_t v = mytail[i - NW];
-                                const int k = (int)word_slot(v);
-                                if (!is_blocked(state[k], word_dist(v))) atomicMax(&post[k], mypost);
+                                const v4u t4 = *(gptr<const v4u>)(mytail + (i - NW));
+                                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                                for (int u = 0; u < 4; u++)
+                                    if (i + u < ncand2) {
+                                        const int k = (int)word_slot(tw[u]);
+                                        if (!is_blocked(state[k], word_dist(tw[u]))) atomicMax(&post[k], mypost);
+                                    }
                             }
                     }
                 }
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
     const int tid_c = tid - 64;                             // waves 1..15: the thread's query of a chunk
     // The parameters of a query are requested PF chunks before its chunk is searched: a chunk takes about a microsecond once
     // the frame's slots have filled up, a load from HBM three
-    constexpr int PF = MODE == MODE_PROJ ? 4 : 2;
+    constexpr int PF = 2;
     RawQ rawq[PF];
 #pragma unroll
     for (int d = 0; d < PF; d++) rawq[d] = raw_load<MODE>(P, S, wave > 0 ? d * FUSED_CHUNK + tid_c : Q);
@@ -1051,8 +1059,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                     dlo[i] = dhi[i] = v4u{0, 0, 0, 0}; pw[i] = 0;
                     if (i < np) {
                         pw[i] = __float_as_uint(c_rec[ppos[i]].w);
-                        if (desc_lds) { dlo[i] = l_desc[2 * ppos[i]]; dhi[i] = l_desc[2 * ppos[i] + 1]; }
-                        else { const int kp = (int)l_kp[ppos[i]]; dlo[i] = gdesc[2 * kp]; dhi[i] = gdesc[2 * kp + 1]; }
+                        const int kp = (int)l_kp[ppos[i]];
+                        dlo[i] = gdesc[2 * kp]; dhi[i] = gdesc[2 * kp + 1];
                     }
                 }
 #pragma unroll
@@ -1840,10 +1848,9 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     // spread over the chip by the split form instead
     constexpr bool BINMASK = MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT;
     constexpr size_t FUSED_LDS_MAX = 160 * 1024 - 1024;       // dynamic part: the kernel's static __shared__ arrays take the rest
-    // (the kernel can keep the frame's descriptors in LDS too; measured no faster -- the search of the first chunks is bound by
+    // (keeping the frame's descriptors in LDS as well was measured no faster -- the search of the first chunks is bound by
     // instruction issue, not by the candidate gathers -- so the 32 B per keypoint stay free for larger frames)
-    const bool fused_desc_lds = false;
-    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK, fused_desc_lds);
+    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK);
     const bool fused_fits = index_ok && fused_lds <= FUSED_LDS_MAX && max_q > 0;
     if (fused_fits && g_win_variant != 1 && g_win_variant != 2 && g_win_variant != 4 &&
         (g_win_variant == 3 || MODE == MODE_INIT || n_inst >= g_win_fused_min_inst || max_q <= g_win_fused_max_q)) {
@@ -1872,7 +1879,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
             }
 #endif
             int32_t *redo = (int32_t *)((char *)ctx->ws2 + o_flags);
-            hipLaunchKernelGGL((fused_kernel<MODE>), dim3((unsigned)ni), dim3(FUSED_THREADS), fused_lds, ctx->stream, R, cfg, (uint32_t *)ctx->ws2, tcap, redo, fused_desc_lds ? 1 : 0, trace);
+            hipLaunchKernelGGL((fused_kernel<MODE>), dim3((unsigned)ni), dim3(FUSED_THREADS), fused_lds, ctx->stream, R, cfg, (uint32_t *)ctx->ws2, tcap, redo, trace);
             HIPCHK(ctx, hipGetLastError());
             // instances with a query that has more candidates than the fused form holds (tcap + 8: very wide windows over crowded
             // keypoints) are searched again by the general form; everywhere else its workgroups return at once
