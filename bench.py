@@ -114,7 +114,7 @@ def cpu_baseline(kfs, n_store):
     multi_pairs_s, multi_pairs = _all_cores(bf, cores, 8.0)
     # C3: one SearchByProjection call (50k map points, th = 3) on one core, then independent instances on all cores
     f, q = synth.proj_instance(seed=synth.SEED0 + 3, n=N_FEAT, n_queries=50000)
-    t1 = time.perf_counter(); orc.search_proj_points(f, q, 3.0, 0.8); proj_ms = (time.perf_counter() - t1) * 1e3
+    t1 = time.perf_counter(); _, _, proj_cmps = orc.search_proj_points(f, q, 3.0, 0.8); proj_ms = (time.perf_counter() - t1) * 1e3
     def proj(k, r):
         orc.search_proj_points(f, q, 3.0, 0.8); return 1
     proj_inst_s, _ = _all_cores(proj, cores, 2.0)
@@ -173,7 +173,7 @@ def cpu_baseline(kfs, n_store):
     return {"value": round(multi_pairs_s * per_pair / 1e9, 4), "unit": "G Hamming cmps/s", "cores": cores, "kind": "port",
             "build": "g++ " + flags, "pairs_per_s": round(multi_pairs_s, 1),
             "single_thread_value": round(single / 1e9, 4), "single_thread_hw_popcnt_value": round(single_popcnt / 1e9, 4),
-            "search_by_projection_single_instance_ms": round(proj_ms, 3),
+            "search_by_projection_single_instance_ms": round(proj_ms, 3), "search_by_projection_cmps": proj_cmps,
             "search_by_projection_all_cores_instances_per_s": round(proj_inst_s, 1),
             "search_by_projection_all_cores_queries_per_s": round(proj_inst_s * 50000, 1),
             "search_by_projection_th1_single_instance_ms": round(proj_th[1.0][0], 3), "search_by_projection_th1_cmps": proj_th[1.0][1],
