@@ -38,6 +38,12 @@ constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
 constexpr int BM_LIST = 320;          // records a wave collects before it settles them (a node with more than 64 takes the generic loop)
 constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
+#ifdef ORBM_DIAG
+__device__ int d_bowm_diag;   // timing only, WRONG results: 1 = records are dropped before they are settled, 2 = no records are made, 4 = accepted matches are not applied
+#define BOWM_DIAG(bit) (diag_bits & (bit))
+#else
+#define BOWM_DIAG(bit) false
+#endif
 
 __device__ __forceinline__ void load_row(gptr<const uint32_t> desc, int idx, uint32_t (&r)[8]) {
     const gptr<const v4u> p = (gptr<const v4u>)desc + 2 * (size_t)idx;
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     __shared__ uint32_t claimed[MAX_N / 32];   // generic loop only: bit per b-side keypoint (a7: vpMapPointMatches set, a8: vbMatched2)
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
+    __shared__ uint32_t s_cand[4];              // candidates named by the records of the tile at hand, one bit each (zero between tiles)
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
@@ -105,17 +112,22 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     const int part = SPLIT ? (int)blockIdx.x - p * splits : 0, nparts = SPLIT ? splits : 1;
     const FrameG A(table[fa[p]]), B(table[fb[p]]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+#ifdef ORBM_DIAG
+    const int diag_bits = d_bowm_diag;
+#endif
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
     if (!SPLIT) for (int i = tid; i < nOut; i += 256) match[i] = -1;
     for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
     if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nmatches = 0;
+    if (tid < 4) s_cand[tid] = 0;
     __syncthreads();
 
     const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     const int thr = MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW;          // :304 / :792
     const float Tf = (float)(256 - 2 * capd);                          // dot > Tf  <=>  distance < capd
+    const int Ti = __float_as_int(Tf);                                 // capd <= 128: Tf >= 0, and a float >= 0 orders like its bits
     uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
     asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
@@ -146,6 +158,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     };
 
     auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815 / :1021-1041
+        if (BOWM_DIAG(4)) { my_matches++; return; }
         if (MODE == 0) match[idxB] = idxA; else match[idxA] = idxB;
         if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[idxB])], 1);
         my_matches++;
@@ -227,6 +240,11 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             }
         }
         unsigned long long todo = __ballot(nA != 0);
+        // nodes (bit = lane that holds the node) none of whose records shares a query or a candidate with another record of
+        // the node, found while the records are made: each of them decides for itself (resolve)
+        unsigned long long simple_nodes = 0;
+        bool node_contested = false;
+        int node_tiles_hit = 0;
         // nodes too large for the record format: the generic loop, first
         for (unsigned long long big = __ballot(nA > REC_MAX_Q || nB > REC_MAX_T); big; big &= big - 1) {
             const int node = __builtin_ctzll(big);
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         // and are settled many nodes at a time, one record per lane: the dependent loads behind a record (keypoint
         // indices, map-point flags, angles) are then paid once per 64 records, not once per node.
         auto resolve = [&](int total) {
+            if (BOWM_DIAG(1)) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the records were written by other lanes of this wave
             __builtin_amdgcn_wave_barrier();
             int start = 0;
@@ -308,6 +327,14 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 start += take;
                 const unsigned long long vmask = __ballot(valid);
                 if (!vmask) continue;
+                if (MODE != 2) {
+                    // the usual round: every node in it is known to have no two records with a query or a candidate in common
+                    const bool simple = in && ((simple_nodes >> (tg & 63)) & 1ull) != 0ull;
+                    if (!__any(valid && !simple)) {
+                        if (valid && rd <= thr) accept_match(idxA, idxB);      // best = this record, second best >= capd
+                        continue;
+                    }
+                }
                 // the lanes of my node: [first, last]
                 const int prev_tg = __shfl_up(tg, 1, 64);
                 const unsigned long long heads = __ballot(in && (lane == 0 || tg != prev_tg));
@@ -407,29 +434,66 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) m = max(max(m, __float_as_int(acc[r])), __float_as_int(acc[r + 1]));
                 m = max(m, __float_as_int(acc[15]));
-                if (__any(m > __float_as_int(Tf))) {
+                if (!BOWM_DIAG(2) && __any(m > Ti)) {
                     // the lane holds query qa0 + col against candidates cb0 + (r & 3) + 8 (r >> 2) + 4 h
                     const uint32_t qbits = (qa0 + (uint32_t)col) << 20, t0 = cb0 + (uint32_t)(4 * h);
+                    const bool hitl = m > Ti;
+                    const unsigned long long hm_all = __ballot(hitl);
+                    const int nhit = (int)__popcll(hm_all);
+                    bool hr[16];
+                    int total = 0;
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const bool hit = acc[r] > Tf;
-                        const unsigned long long hm = __ballot(hit);
-                        if (!hm) continue;
-                        if (hit) {
-                            const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
-                            const int pos = n_rec + (int)__popcll(hm & ((1ull << lane) - 1ull));   // the wave counts its own records
-                            if (pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + (uint32_t)((r & 3) + 8 * (r >> 2))); tags[pos] = (uint8_t)D.node; }
+                        hr[r] = __float_as_int(acc[r]) > Ti;
+                        total += (int)__popcll(__ballot(hr[r]));
+                    }
+                    node_tiles_hit++;
+                    if (total == nhit) {
+                        // the usual tile: no lane has two hits, so a lane's hit is its maximum and its register is read off
+                        // the sixteen compare masks (lane-mask ORs on the scalar unit); every record of the tile in one go
+                        const bool b0 = hr[1] | hr[3] | hr[5] | hr[7] | hr[9] | hr[11] | hr[13] | hr[15];
+                        const bool b1 = hr[2] | hr[3] | hr[6] | hr[7] | hr[10] | hr[11] | hr[14] | hr[15];
+                        const bool b2 = hr[4] | hr[5] | hr[6] | hr[7] | hr[12] | hr[13] | hr[14] | hr[15];
+                        const bool b3 = hr[8] | hr[9] | hr[10] | hr[11] | hr[12] | hr[13] | hr[14] | hr[15];
+                        const uint32_t code = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 8u : 0u) | (b3 ? 16u : 0u);   // (r & 3) + 8 (r >> 2)
+                        const uint32_t d = (uint32_t)((256 - (int)__int_as_float(m)) >> 1);
+                        const int pos = n_rec + (int)__popcll(hm_all & ((1ull << lane) - 1ull));
+                        if (hitl && pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + code); tags[pos] = (uint8_t)D.node; }
+                        n_rec += nhit;
+                        // two records of this tile with one query (its two lanes) or one candidate (the bit was set before)?
+                        const uint32_t bit = 1u << (code + (uint32_t)(4 * h));
+                        uint32_t old = 0;
+                        if (hitl) old = atomicOr(&s_cand[wave], bit);
+                        const bool dup = __any(hitl && (old & bit) != 0u) || ((uint32_t)hm_all & (uint32_t)(hm_all >> 32)) != 0u;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) s_cand[wave] = 0;
+                        if (dup || node_tiles_hit > 1) node_contested = true;   // (records of two tiles of one node: not looked at, taken as shared)
+                    } else {
+                        node_contested = true;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const unsigned long long hm = __ballot(hr[r]);
+                            if (!hm) continue;
+                            if (hr[r]) {
+                                const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
+                                const int pos = n_rec + (int)__popcll(hm & ((1ull << lane) - 1ull));   // the wave counts its own records
+                                if (pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + (uint32_t)((r & 3) + 8 * (r >> 2))); tags[pos] = (uint8_t)D.node; }
+                            }
+                            n_rec += (int)__popcll(hm);
                         }
-                        n_rec += (int)__popcll(hm);
                     }
                 }
             }
             if (!D.last) continue;
+            const bool was_contested = node_contested;
+            node_contested = false; node_tiles_hit = 0;
             if (n_rec - node_start > 64) {
                 // more relevant pairs than lanes: this node takes the generic loop, its records are dropped
                 generic_node(D.offA, nAs, D.offB, nBs);
                 n_rec = node_start;
             } else {
+                if (!was_contested) simple_nodes |= 1ull << D.node;
                 node_start = n_rec;
             }
             if (node_start > BM_LIST - 64) {                   // the next node may need 64 slots
@@ -479,6 +543,10 @@ int orbm_bow_cap(float ratio) {
     while (c <= 256 && !((float)c * ratio > (float)ORBM_TH_LOW)) c++;
     return c;
 }
+
+#ifdef ORBM_DIAG
+extern "C" void orbm__bowm_diag(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_bowm_diag), &bits, sizeof(int)); }
+#endif
 
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,
                      int check_ori, int stride, int32_t *dm, int32_t *dc, int splits, int *pair_acc, int only_stereo,

@@ -1470,7 +1470,14 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             // queries' interest in a slot must be visible to whoever wants to take it (claimable slots are posted above)
             constexpr bool USES_SECOND = MODE == MODE_PROJ || MODE == MODE_INIT;
             const bool live = unresolved && bestIdx >= 0 && bestDist <= thr;
-            if (live && USES_SECOND && bestIdx2 >= 0) atomicMin(&post[bestIdx2], (uint32_t)tid);
+            // (as in fused_kernel: the second-best free slot matters only to a query whose ratio test does not pass on
+            // distances now -- it can only get worse, so a test that passes now passes with any later second best)
+            bool second_matters = false;
+            if (USES_SECOND && live && bestIdx2 >= 0) {
+                if (MODE == MODE_PROJ) second_matters = (float)bestDist > __fmul_rn(P.ratio, (float)bestDist2);
+                else second_matters = !((float)bestDist < __fmul_rn((float)bestDist2, P.ratio));
+            }
+            if (second_matters) atomicMin(&post[bestIdx2], (uint32_t)tid);
             __syncthreads();
             // ---- contested? ---------------------------------------------------------------------------
             // The outcome is a function of the best and (where a ratio test reads it) the second-best free candidate, and
@@ -1480,7 +1487,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             bool contested = false;
             if (live) {
                 contested = post[bestIdx] < (uint32_t)tid;
-                if (USES_SECOND && bestIdx2 >= 0 && post[bestIdx2] < (uint32_t)tid) contested = true;
+                if (second_matters && post[bestIdx2] < (uint32_t)tid) contested = true;
             }
             if (wg_any(contested)) {
                 if (contested) {
@@ -1848,8 +1855,9 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     // spread over the chip by the split form instead
     constexpr bool BINMASK = MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT;
     constexpr size_t FUSED_LDS_MAX = 160 * 1024 - 1024;       // dynamic part: the kernel's static __shared__ arrays take the rest
-    // (keeping the frame's descriptors in LDS as well was measured no faster -- the search of the first chunks is bound by
-    // instruction issue, not by the candidate gathers -- so the 32 B per keypoint stay free for larger frames)
+    // (keeping the frame's descriptors in LDS as well was measured no faster, for a6 / a11 batches -- the search of the first
+    // chunks is bound by instruction issue, not by the candidate gathers -- and for a5 alone, whose few hundred valid queries
+    // walk some thirty candidates each, one after the other: 127 against 129 us per call; the 32 B per keypoint stay free)
     const size_t fused_lds = fused_lds_bytes(cfg, BINMASK);
     const bool fused_fits = index_ok && fused_lds <= FUSED_LDS_MAX && max_q > 0;
     if (fused_fits && g_win_variant != 1 && g_win_variant != 2 && g_win_variant != 4 &&
