@@ -38,11 +38,15 @@ constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
 constexpr int BM_LIST = 320;          // records a wave collects before it settles them (a node with more than 64 takes the generic loop)
 constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
+constexpr int BIN_ROWS = 4096;        // match rows up to this length keep their matches' rotation bins in LDS for the filter pass
 #ifdef ORBM_DIAG
 __device__ int d_bowm_diag;   // timing only, WRONG results: 1 = records are dropped before they are settled, 2 = no records are made, 4 = accepted matches are not applied
 #define BOWM_DIAG(bit) (diag_bits & (bit))
+__device__ unsigned long long d_bowm_trace[64 * 8];   // wall-clock stamps of every 128th workgroup's wave 0: start, set-up done, nodes looked up, tiles done, records settled, end
+#define BOWM_STAMP(k) do { if ((blockIdx.x & 127) == 0 && blockIdx.x < 64 * 128 && tid == 0) d_bowm_trace[(blockIdx.x >> 7) * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define BOWM_DIAG(bit) false
+#define BOWM_STAMP(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ void load_row(gptr<const uint32_t> desc, int idx, uint32_t (&r)[8]) {
@@ -96,7 +100,7 @@ __device__ __forceinline__ v8i expand_fp4(uint32_t w, uint32_t ones) {
 // batches: a single SearchByBoW call would otherwise run on one CU); the match rows were pre-set to -1 by the caller, histogram
 // and count go to pair_acc (32 ints per pair) and bow_finish_kernel (bow.hip) applies the rotation filter afterwards.
 template <int MODE, bool SPLIT>
-__global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                    const int32_t *__restrict__ fb, float ratio, int capd, int check_ori, int stride,
                                                    int32_t *__restrict__ match_all, int32_t *__restrict__ counts, int splits,
                                                    int *__restrict__ pair_acc, int only_stereo, const float *__restrict__ f12all,
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
     __shared__ uint32_t s_cand[4];              // candidates named by the records of the tile at hand, one bit each (zero between tiles)
+    __shared__ __align__(16) uint8_t s_bin[SPLIT ? 16 : BIN_ROWS];   // rotation bin of the match in row i of the pair's match row, 0xFF = none (rows < BIN_ROWS)
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int nmatches;
@@ -115,14 +120,18 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
 #ifdef ORBM_DIAG
     const int diag_bits = d_bowm_diag;
 #endif
+    BOWM_STAMP(0);
     const int nOut = MODE == 0 ? B.n : A.n;
     int32_t *match = match_all + (size_t)p * stride;
     if (!SPLIT) for (int i = tid; i < nOut; i += 256) match[i] = -1;
+    const bool bins_in_lds = !SPLIT && check_ori && nOut <= BIN_ROWS;
+    if (bins_in_lds) for (int i = tid * 16; i < nOut; i += 256 * 16) *reinterpret_cast<v4u *>(&s_bin[i]) = v4u{~0u, ~0u, ~0u, ~0u};
     for (int i = tid; i < (B.n + 31) / 32; i += 256) claimed[i] = 0;
     if (tid < ORBM_HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nmatches = 0;
     if (tid < 4) s_cand[tid] = 0;
     __syncthreads();
+    BOWM_STAMP(1);
 
     const gptr<const float> angB = MODE == 0 ? B.angle_raw : B.angle;  // :323 reads F.mvKeys on the frame side
     const int thr = MODE == 1 ? ORBM_TH_LOW - 1 : ORBM_TH_LOW;          // :304 / :792
@@ -160,7 +169,11 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
     auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815 / :1021-1041
         if (BOWM_DIAG(4)) { my_matches++; return; }
         if (MODE == 0) match[idxB] = idxA; else match[idxA] = idxB;
-        if (check_ori) atomicAdd(&hist[rot_bin(A.angle[idxA], angB[idxB])], 1);
+        if (check_ori) {
+            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+            atomicAdd(&hist[bin], 1);
+            if (bins_in_lds) s_bin[MODE == 0 ? idxB : idxA] = (uint8_t)bin;
+        }
         my_matches++;
     };
 
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
             }
         }
         unsigned long long todo = __ballot(nA != 0);
+        BOWM_STAMP(2);
         // nodes (bit = lane that holds the node) none of whose records shares a query or a candidate with another record of
         // the node, found while the records are made: each of them decides for itself (resolve)
         unsigned long long simple_nodes = 0;
@@ -456,9 +470,9 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                         const bool b2 = hr[4] | hr[5] | hr[6] | hr[7] | hr[12] | hr[13] | hr[14] | hr[15];
                         const bool b3 = hr[8] | hr[9] | hr[10] | hr[11] | hr[12] | hr[13] | hr[14] | hr[15];
                         const uint32_t code = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 8u : 0u) | (b3 ? 16u : 0u);   // (r & 3) + 8 (r >> 2)
-                        const uint32_t d = (uint32_t)((256 - (int)__int_as_float(m)) >> 1);
-                        const int pos = n_rec + (int)__popcll(hm_all & ((1ull << lane) - 1ull));
-                        if (hitl && pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + code); tags[pos] = (uint8_t)D.node; }
+                        const uint32_t d13 = (uint32_t)(256 - (int)__int_as_float(m)) << 12;     // distance << 13 (the dot is even)
+                        const int pos = n_rec + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm_all >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm_all, 0u));
+                        if (hitl && pos < BM_LIST) { list[pos] = (qbits | d13) + (t0 + code); tags[pos] = (uint8_t)D.node; }
                         n_rec += nhit;
                         // two records of this tile with one query (its two lanes) or one candidate (the bit was set before)?
                         const uint32_t bit = 1u << (code + (uint32_t)(4 * h));
@@ -501,7 +515,9 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
                 node_start = 0; n_rec = 0;
             }
         }
+        BOWM_STAMP(3);
         resolve(node_start);                                  // before the lanes' node table moves on to the next 64 nodes
+        BOWM_STAMP(4);
     }
     if (my_matches) atomicAdd(&nmatches, my_matches);
     __syncthreads();
@@ -520,6 +536,13 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         __syncthreads();
         const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
         int removed = 0;
+        if (bins_in_lds) {
+            // (a row is matched at most once -- vpMapPointMatches[idxF] / vpMatches12[idx1] are claimed -- so its bin is the one kept here)
+            for (int i = tid; i < nOut; i += 256) {
+                const int bin = (int)s_bin[i];
+                if (bin != 0xFF && bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }   // :368-381 / :836-849
+            }
+        } else
         for (int i = tid; i < nOut; i += 256) {
             const int m = match[i];
             if (m < 0) continue;
@@ -531,6 +554,7 @@ __global__ __launch_bounds__(256) void bowm_kernel(const FrameDev *__restrict__ 
         __syncthreads();
     }
     if (tid == 0) counts[p] = nmatches;
+    BOWM_STAMP(5);
 }
 
 }  // namespace
@@ -546,6 +570,7 @@ int orbm_bow_cap(float ratio) {
 
 #ifdef ORBM_DIAG
 extern "C" void orbm__bowm_diag(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_bowm_diag), &bits, sizeof(int)); }
+extern "C" void orbm__bowm_trace(unsigned long long *out) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d_bowm_trace), sizeof(unsigned long long) * 64 * 8); }
 #endif
 
 int orbm_launch_bowm(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *dfa, const int32_t *dfb, float ratio, int capd,

@@ -35,4 +35,16 @@ for bits, what in ((0, "everything"), (4, "matches not applied"), (1, "records n
                 best = min(best, e0.elapsed_time(e1))
         print("%-22s %-10s %.3f ms  %.2f M pairs/s" % (what, name, best, P / best / 1e3), flush=True)
 L.orbm__bowm_diag(0)
+import ctypes
+buf = (ctypes.c_ulonglong * 512)()
+for name, (fa, fb) in mixes.items():
+    tfa = torch.tensor(fa, device=dev); tfb = torch.tensor(fb, device=dev)
+    for rep in range(2):
+        ctx.search_bow_dev(1, P, tfa.data_ptr(), tfb.data_ptr(), 0.75, True, bench.N_FEAT, match.data_ptr(), counts.data_ptr())
+    torch.cuda.synchronize()
+    L.orbm__bowm_trace(buf)
+    t = np.array(buf[:], dtype=np.float64).reshape(64, 8) / 100.0      # 100 MHz wall clock -> us
+    d = np.diff(t[:, :6], axis=1)
+    print("%-10s wave 0 of 64 sampled workgroups, us: set-up %.2f | node look-up %.2f | tiles %.2f | settle %.2f | end %.2f | life %.2f; kernel span %.1f"
+          % (name, *d.mean(axis=0), (t[:, 5] - t[:, 0]).mean(), t[:, 5].max() - t[:, 0].min()), flush=True)
 ctx.close()
