@@ -464,12 +464,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                     node_tiles_hit++;
                     if (total == nhit) {
                         // the usual tile: no lane has two hits, so a lane's hit is its maximum and its register is read off
-                        // the sixteen compare masks (lane-mask ORs on the scalar unit); every record of the tile in one go
-                        const bool b0 = hr[1] | hr[3] | hr[5] | hr[7] | hr[9] | hr[11] | hr[13] | hr[15];
-                        const bool b1 = hr[2] | hr[3] | hr[6] | hr[7] | hr[10] | hr[11] | hr[14] | hr[15];
-                        const bool b2 = hr[4] | hr[5] | hr[6] | hr[7] | hr[12] | hr[13] | hr[14] | hr[15];
-                        const bool b3 = hr[8] | hr[9] | hr[10] | hr[11] | hr[12] | hr[13] | hr[14] | hr[15];
-                        const uint32_t code = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 8u : 0u) | (b3 ? 16u : 0u);   // (r & 3) + 8 (r >> 2)
+                        // the sixteen compare masks (one select each: the scalar unit is as busy as the vector unit in this
+                        // kernel, so not by OR-ing the masks there); every record of the tile in one go
+                        uint32_t code = 0;                                   // (r & 3) + 8 (r >> 2) of the lane's hit
+#pragma unroll
+                        for (int r = 1; r < 16; r++) code = hr[r] ? (uint32_t)((r & 3) + 8 * (r >> 2)) : code;
                         const uint32_t d13 = (uint32_t)(256 - (int)__int_as_float(m)) << 12;     // distance << 13 (the dot is even)
                         const int pos = n_rec + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm_all >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm_all, 0u));
                         if (hitl && pos < BM_LIST) { list[pos] = (qbits | d13) + (t0 + code); tags[pos] = (uint8_t)D.node; }
