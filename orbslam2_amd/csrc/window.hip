@@ -35,6 +35,13 @@
 
 namespace {
 
+#ifdef ORBM_DIAG
+__device__ unsigned long long d_win_stamps[128];   // timing only: wall-clock stamps of instance 0 of the split form's two kernels
+#define WIN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) d_win_stamps[(k)] = wall_clock64(); } while (0)
+#else
+#define WIN_STAMP(k) do { } while (0)
+#endif
+
 enum { MODE_LAST = 0, MODE_KF = 1, MODE_SIM3 = 2, MODE_INIT = 3, MODE_PROJ = 10 };
 
 constexpr int WIN_MAX_N = 8160;       // slot state lives in LDS: 5 x 4 B per keypoint (+ 256 B) within 160 KB
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     // ---- the index.  Bucket b's run is c_rec[c_off[b + 1] .. c_off[b + 2]): counters sit at c_off[b + 2] (two u16 per
     // atomic word), are turned into start positions by an exclusive scan and advanced to END positions by the scatter.
     uint32_t *cnt32 = lds;
+    WIN_STAMP(0);
     for (int i = tid; i < offn / 2; i += COLLECT_THREADS) cnt32[i] = 0;
     __syncthreads();
     const int T = (int)F.cell_off[ORBM_GRID_CELLS];
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         }
     }
     __syncthreads();
+    WIN_STAMP(1);
     {
         const int per = (total + COLLECT_THREADS - 1) / COLLECT_THREADS;
         const int i0 = min(total, tid * per), i1 = min(total, i0 + per);
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         if (tid == 0) { c_off[0] = 0; c_off[1] = 0; }
     }
     __syncthreads();
+    WIN_STAMP(2);
     for (int j = tid; j < T; j += COLLECT_THREADS) {
         const v4f rc = F.cell_rec[j];
         const uint32_t w = __float_as_uint(rc.w);
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         }
     }
     __syncthreads();
+    WIN_STAMP(3);
     const QSrc S = query_source<MODE>(P, inst);
     const bool stereo_gate = has_stereo_gate<MODE>(S);
     const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
@@ -404,6 +415,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
             l_perm[l_bucket[cls[h]] + rank[h]] = (uint16_t)(h * qt + tid);
         }
         __syncthreads();
+        WIN_STAMP(4);
       for (int h = 0; h < groups && wave < QW && !(cost_exact & 8); h++) {
         const int group = h == 0 ? wave : 2 * QW - 1 - wave;
         const int qi = sc * SUPER + (int)l_perm[group * 64 + lane];
@@ -501,6 +513,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
         }
       }
         __syncthreads();     // l_perm and l_bucket are rewritten by the next super-chunk
+        WIN_STAMP(5);
     }
 }
 
@@ -1302,6 +1315,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     // Slots: a keypoint is named by its position j in the cell-ordered stream: that is what ranks candidates of equal
     // distance (the reference's visit order), so candidate words order themselves.
     const int n_slots = (int)F.cell_off[ORBM_GRID_CELLS];
+    if (PRE) WIN_STAMP(16);
     for (int i = tid; i < n_slots; i += nthr) {
         uint32_t s0;
         const int kp = (int)F.cell_idx[i];
@@ -1317,6 +1331,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     if (tid == 0) *nmatch = 0;
     if (tid < 3) s_any[tid] = 0;            // wg_any's flags (below)
     __syncthreads();
+    if (PRE) WIN_STAMP(17);
 
     const bool use_hist = P.check_ori && (MODE == MODE_LAST || MODE == MODE_KF || MODE == MODE_INIT) &&
                           (MODE == MODE_INIT || S.QS.angle != nullptr);
@@ -1422,6 +1437,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
         if (!wg_any(unresolved)) return;
 
         int round = 0;
+        if (PRE) WIN_STAMP(20);
         while (true) {
             uint32_t *post = (round & 1) ? post1 : post0;
             uint32_t *post_next = (round & 1) ? post0 : post1;
@@ -1561,6 +1577,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
             }
             // the other post buffer is idle in this phase (decide only reads `post`): clear it for the next round
             for (int i = tid; i < n_slots; i += nthr) post_next[i] = NOPOST;
+            if (PRE && round < 40) WIN_STAMP(21 + round);
             if (!wg_any(unresolved)) break;
             round++;
         }
@@ -1640,6 +1657,10 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
                 }
             const int nlive = pre[SCAN_U * NW - 1] + cnts[SCAN_U * NW - 1];
             __syncthreads();
+            WIN_STAMP(18);
+#ifdef ORBM_DIAG
+            if (blockIdx.x == 0 && tid == 0) d_win_stamps[70] = (unsigned long long)nlive;
+#endif
             for (int c0 = 0; c0 < nlive; c0 += nthr) {
                 const int li = c0 + tid;
                 const int qi = li < nlive ? sb + (int)qlist[li] : Q;
@@ -1678,6 +1699,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
 
     if (my_matches) atomicAdd(nmatch, my_matches);
     __syncthreads();
+    if (PRE) WIN_STAMP(62);
     if (use_hist) {
         if (tid == 0) {
             int i1, i2, i3;
@@ -1724,6 +1746,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
         for (int i = tid; i < n_slots; i += nthr) out[F.cell_idx[i]] = owner[i];
     }
     if (tid == 0) P.counts[inst] = *nmatch;
+    if (PRE) WIN_STAMP(63);
 }
 
 // a12: claim-free best-1 (SearchBySim3 / Fuse inner loops).  Queries are independent: one lane per query, grid =
@@ -2043,6 +2066,13 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
 }  // namespace
 
 // tuning / test knob (not part of the public ABI): see g_win_variant
+#ifdef ORBM_DIAG
+extern "C" void orbm__window_stamps(unsigned long long *out, int clear) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(d_win_stamps), sizeof(unsigned long long) * 128);
+    if (clear) { static unsigned long long z[128]; (void)hipMemcpyToSymbol(HIP_SYMBOL(d_win_stamps), z, sizeof(z)); }
+}
+#endif
 extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
 extern "C" void orbm__window_fused_rule(int min_inst, int max_q) { g_win_fused_min_inst = min_inst; g_win_fused_max_q = max_q; }
 #ifdef ORBM_DIAG
