@@ -637,7 +637,8 @@ def main():
                                  "kernel_ms = HIP events around one orbm_allpairs_batch call on its stream, averaged over the timed "
                                  "region: the matching kernel plus its counter memset and the two record-compaction kernels "
                                  "(profiles/: < 1 % of it), so `achieved` is a slight under-statement of the kernel alone. traffic: "
-                                 "not measurable inside this run (PMC counters need rocprofv3); profiles/r02_* holds the counter pass. "
+                                 "PMC counters cannot be read inside this run; the field quotes the committed rocprofv3 counter pass "
+                                 "taken on the same store size and pairs per launch (traffic_source), null when there is none. "
                                  "vs_integer_popcount_roofline = achieved cmps/s over the 3.277 T cmps/s that bound the xor + popcount "
                                  "form of this kernel (roofline_popcount_form: that form, same run)"},
         }
