@@ -620,7 +620,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                          const int32_t *__restrict__ fb, int check_ori, int stride,
                                                          int32_t *__restrict__ match_all, int32_t *__restrict__ counts,
-                                                         const int *__restrict__ pair_acc) {
+                                                         const int *__restrict__ pair_acc, int encoded) {
+    // encoded (the matrix-core form with the orientation check on): a match was written as index | rotation bin << 16, so this
+    // pass needs neither frame's angles: it keeps or drops by the bin and leaves the plain index
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int removed_all;
@@ -641,17 +643,40 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
         __syncthreads();
         const int k1 = keep[0], k2 = keep[1], k3 = keep[2];
         int removed = 0;
-        for (int i = tid; i < nOut; i += 256) {
-            const int m = match[i];
-            if (m < 0) continue;
-            const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
-            const int bin = rot_bin(A.angle[idxA], angB[idxB]);
-            if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }
+        if (encoded) {
+            for (int i = tid; i < nOut; i += 256) {
+                const int m = match[i];
+                if (m < 0) continue;
+                const int bin = m >> 16;
+                if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }
+                else match[i] = m & 0xFFFF;
+            }
+        } else {
+            for (int i = tid; i < nOut; i += 256) {
+                const int m = match[i];
+                if (m < 0) continue;
+                const int idxA = MODE == 0 ? m : i, idxB = MODE == 0 ? i : m;
+                const int bin = rot_bin(A.angle[idxA], angB[idxB]);
+                if (bin != k1 && bin != k2 && bin != k3) { match[i] = -1; removed++; }
+            }
         }
         if (removed) atomicAdd(&removed_all, removed);
         __syncthreads();
     }
     if (tid == 0) counts[p] = pair_acc[p * 32 + 30] - removed_all;
+}
+
+// the split forms start from match rows of -1 and zeroed per-pair accumulators: one launch for both (two memsets are two
+// launches, and a small batch is a handful of launches in all)
+__global__ __launch_bounds__(256) void bow_init_kernel(int32_t *__restrict__ match, size_t n_match, int *__restrict__ acc, int n_acc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < n_match; k += nthreads) match[k] = -1;
+    for (size_t k = i; k < (size_t)n_acc; k += nthreads) acc[k] = 0;
+}
+void launch_bow_init(orbm_ctx *ctx, int32_t *match, size_t n_match, int *acc, int n_acc) {
+    const size_t most = std::max(n_match, (size_t)n_acc);
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(4096, (most + 1023) / 1024));
+    hipLaunchKernelGGL(bow_init_kernel, dim3(grid), dim3(256), 0, ctx->stream, match, n_match, acc, n_acc);
 }
 
 // tuning / test knob: 0 = auto (batches of g_bow_split_below pairs and more: the matrix-core form of bowm.hip for a7 / a8,
@@ -661,6 +686,7 @@ __global__ __launch_bounds__(256) void bow_finish_kernel(const FrameDev *__restr
 int g_bow_variant = 0;
 int g_bow_split_below = 2048;   // batches of fewer pairs share each pair between several workgroups
 int g_bowm_wgs = 4096;          // matrix-core form: workgroups a small batch is spread over
+constexpr int BOWM_SPLIT_BELOW = 900;   // ... below this many pairs (scripts/bow64_perf.py: 512 pairs 0.038 ms split / 0.041 whole, 1024 pairs 0.053 / 0.051)
 
 // Allocation-free variant (orbm_search_bow_batch_noalloc): the per-pair accumulators of the split path (30 histogram bins +
 // the match count, 32 ints per pair) live in this file-scope device array instead of the context's grow-only workspace.
@@ -713,7 +739,6 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
         (rc = io.in(f12, (size_t)n_pairs * 36, &df12)) || (rc = io.in(epipole, (size_t)n_pairs * 8, &dep)) ||
         (rc = io.out(match, out_elems * 4, &dm)) || (rc = io.out(counts, (size_t)n_pairs * 4, &dc)))
         return rc;
-    if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
     // One workgroup per pair needs a few thousand pairs to fill the chip (a pair keeps its workgroup 0.1-0.2 ms).  Below that
     // several workgroups share a pair's nodes, about 4096 workgroups in all and at most 32 (16) per pair; up to 96 pairs the
     // candidates-on-lanes kernel is the faster of the two forms, above the queries-on-lanes kernel (scripts/bow64_perf.py:
@@ -721,18 +746,20 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
     const bool split_queries_on_lanes = g_bow_variant == 2 || (g_bow_variant != 1 && n_pairs > 96);
     // the matrix-core form keeps a workgroup about 50 us on a pair (a wave walks 25 nodes one after the other): below
     // g_bowm_wgs workgroups in all a pair's nodes are dealt to several workgroups (at most 16)
-    const int splits = use_mfma ? (n_pairs >= g_bow_split_below ? 1 : std::max(1, std::min(16, g_bowm_wgs / n_pairs)))
+    const int splits = use_mfma ? (n_pairs >= std::min(g_bow_split_below, BOWM_SPLIT_BELOW) ? 1 : std::max(1, std::min(16, g_bowm_wgs / n_pairs)))
                        : one_wg_per_pair ? 1
                        : std::max(2, std::min(split_queries_on_lanes ? 16 : 32, (4096 + n_pairs - 1) / n_pairs));
     dim3 block(256);
+    // (the kernels with one workgroup per pair set their own match rows; in host mode rows beyond a pair's own length are
+    // part of what is copied back, so the whole buffer is set there)
+    if (splits == 1 && !io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));
     if (use_mfma) {
         int *acc = nullptr;
         if (splits > 1) {
             rc = orbm_ws2_reserve(ctx, (size_t)n_pairs * 32 * sizeof(int));
             if (rc) return rc;
             acc = (int *)ctx->ws2;
-            HIPCHK(ctx, hipMemsetAsync(acc, 0, (size_t)n_pairs * 32 * sizeof(int), ctx->stream));
-            if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
+            launch_bow_init(ctx, (int32_t *)dm, out_elems, acc, n_pairs * 32);
         }
         rc = orbm_launch_bowm(ctx, mode, n_pairs, (const int32_t *)dfa, (const int32_t *)dfb, ratio, capd, check_ori, stride, (int32_t *)dm,
                               (int32_t *)dc, splits, acc, only_stereo, (const float *)df12, (const float *)dep);
@@ -741,13 +768,13 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
             dim3 fgrid(n_pairs);
             if (mode == 0)
                 hipLaunchKernelGGL((bow_finish_kernel<0>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
-                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc, check_ori ? 1 : 0);
             else if (mode == 2)
                 hipLaunchKernelGGL((bow_finish_kernel<2>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
-                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc, check_ori ? 1 : 0);
             else
                 hipLaunchKernelGGL((bow_finish_kernel<1>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, (const int32_t *)dfb,
-                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);
+                                   check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc, check_ori ? 1 : 0);
         }
     } else if (splits == 1) {
         dim3 grid(n_pairs);
@@ -763,8 +790,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
             if (rc) return rc;
         }
         int *acc = static_acc ? static_acc : (int *)ctx->ws2;
-        HIPCHK(ctx, hipMemsetAsync(acc, 0, (size_t)n_pairs * 32 * sizeof(int), ctx->stream));
-        if (io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(dm, 0xFF, out_elems * 4, ctx->stream));   // host mode did it above
+        launch_bow_init(ctx, (int32_t *)dm, out_elems, acc, n_pairs * 32);
         dim3 grid(n_pairs * splits), fgrid(n_pairs);
 #define LAUNCH(M)                                                                                              \
     do {                                                                                                       \
@@ -772,7 +798,7 @@ int launch_bow(orbm_ctx *ctx, int mode, int n_pairs, const int32_t *frame_a, con
                            (const int32_t *)dfb, ratio, check_ori, only_stereo, (const float *)df12, (const float *)dep, \
                            stride, (int32_t *)dm, (int32_t *)dc, splits, acc);                                  \
         hipLaunchKernelGGL((bow_finish_kernel<M>), fgrid, block, 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa,   \
-                           (const int32_t *)dfb, check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc);   \
+                           (const int32_t *)dfb, check_ori, stride, (int32_t *)dm, (int32_t *)dc, (const int *)acc, 0);   \
     } while (0)
         if (mode == 0) LAUNCH(0); else if (mode == 1) LAUNCH(1); else LAUNCH(2);
 #undef LAUNCH

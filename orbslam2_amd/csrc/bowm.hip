@@ -168,12 +168,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 
     auto accept_match = [&](int idxA, int idxB) {                      // :312-330 / :798-815 / :1021-1041
         if (BOWM_DIAG(4)) { my_matches++; return; }
-        if (MODE == 0) match[idxB] = idxA; else match[idxA] = idxB;
+        int enc = 0;                               // SPLIT: the bin travels with the match to bow_finish_kernel (index < 65536)
         if (check_ori) {
             const int bin = rot_bin(A.angle[idxA], angB[idxB]);
             atomicAdd(&hist[bin], 1);
             if (bins_in_lds) s_bin[MODE == 0 ? idxB : idxA] = (uint8_t)bin;
+            if (SPLIT) enc = bin << 16;
         }
+        if (MODE == 0) match[idxB] = idxA | enc; else match[idxA] = idxB | enc;
         my_matches++;
     };
 
