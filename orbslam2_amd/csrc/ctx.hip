@@ -546,7 +546,11 @@ int orbm_frame_set_mp_flags(orbm_ctx *ctx, int32_t id, const uint8_t *mp_flags) 
     if (rc) return rc;
     if (!mp_flags) return orbm_fail(ctx, ORBM_EINVAL, "mp_flags is null");
     const FrameDev &f = ctx->h_frames[id];
-    HIPCHK(ctx, hipMemcpyAsync(f.mp_flags, mp_flags, (size_t)f.n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // through the pinned mirror when it is large enough (a copy from pageable memory is staged by the runtime, at twice the cost)
+    const void *src = mp_flags;
+    if (ctx->pin && (size_t)f.n <= ctx->pin_bytes) { memcpy(ctx->pin, mp_flags, (size_t)f.n); src = ctx->pin; }
+    HIPCHK(ctx, hipMemcpyAsync(f.mp_flags, src, (size_t)f.n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ORBM_OK;
 }

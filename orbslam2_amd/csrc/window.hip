@@ -53,7 +53,8 @@ struct WinParams {
     const int32_t *frame_ids;
     const int32_t *qset_ids;     // MODE_INIT: id of frame 1 (the query frame)
     const uint8_t *slot_flags;   // nullable, n_inst x stride
-    float *prev_xy;              // MODE_INIT only
+    const float *prev_xy;        // MODE_INIT only: vbPrevMatched as it comes in
+    float *prev_out;             // ... and where the matched entries are written (:684-686); the others are left alone
     int32_t *out;                // owner (n_inst x stride) | MODE_INIT: matches12
     int32_t *counts;
     float th, ratio;
@@ -1260,7 +1261,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
     if (MODE == MODE_INIT) {
         for (int i = tid; i < Q; i += FUSED_THREADS) {                                    // :684-686
             const int m = out[i];
-            if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
+            if (m >= 0) { P.prev_out[2 * i] = F.x[m]; P.prev_out[2 * i + 1] = F.y[m]; }
         }
     } else {
         for (int i = tid; i < n; i += FUSED_THREADS) out[i] = -1;                         // keypoints outside the grid are never candidates
@@ -1737,7 +1738,7 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
     if (MODE == MODE_INIT) {
         for (int i = tid; i < Q; i += nthr) {                                             // :684-686
             const int m = out[i];
-            if (m >= 0) { P.prev_xy[2 * i] = F.x[m]; P.prev_xy[2 * i + 1] = F.y[m]; }
+            if (m >= 0) { P.prev_out[2 * i] = F.x[m]; P.prev_out[2 * i + 1] = F.y[m]; }
         }
     } else {
         // keypoints outside the grid (no stream position) are never candidates: -1
@@ -2050,7 +2051,10 @@ int run_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t *frame, 
         (rc = io.in(slot_flags, out_elems, &dsf)) || (rc = io.out(owner, out_elems * 4, &down)) ||
         (rc = io.out(counts, (size_t)n_inst * 4, &dc)))
         return rc;
-    if (!io_on_device && out_elems) HIPCHK(ctx, hipMemsetAsync(down, 0xFF, out_elems * 4, ctx->stream));
+    // rows beyond a frame's n are part of what host mode copies back: -1 there (the kernels write a frame's own n rows)
+    bool ragged = false;
+    if (!io_on_device) for (int k = 0; k < n_inst && !ragged; k++) ragged = ctx->h_frames[frame[k]].n != stride;
+    if (ragged && out_elems) HIPCHK(ctx, hipMemsetAsync(down, 0xFF, out_elems * 4, ctx->stream));
     WinParams P;
     memset(&P, 0, sizeof P);
     P.frames = ctx->d_frames; P.qsets = ctx->d_qsets;
@@ -2196,29 +2200,31 @@ extern "C" int orbm_search_init(orbm_ctx *ctx, int32_t frame1, int32_t frame2, f
     if (n1 == 0) return 0;
     if (n2 > WIN_MAX_N) return orbm_fail(ctx, ORBM_ELIMIT, "search_init: frame 2 has %d keypoints (limit %d)", n2, WIN_MAX_N);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    rc = orbm_ws_reserve(ctx, (size_t)n1 * 12 + 4096);
+    // one pinned copy in, one out (as every other entry point; separate copies from and to pageable memory were a third of
+    // this call).  vbPrevMatched is in / out: it goes in whole, the kernel writes the matched entries to a second array and
+    // the host puts those over the caller's.
+    rc = orbm_ws_reserve(ctx, (size_t)n1 * 20 + 4096);
     if (rc) return rc;
-    char *w = (char *)ctx->ws;
-    int32_t *d_ids = (int32_t *)w;                 // [frame2, frame1]
-    int32_t *d_count = (int32_t *)(w + 256);
-    float *d_prev = (float *)(w + 512);
-    int32_t *d_m12 = (int32_t *)(w + 512 + (((size_t)n1 * 8 + 255) / 256) * 256);
+    IoStage io(ctx, 0);
     const int32_t ids[2] = {frame2, frame1};
-    HIPCHK(ctx, hipMemcpyAsync(d_ids, ids, 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_prev, prev_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> prev_new((size_t)n1 * 2);
+    int32_t count = 0;
+    const void *d_ids, *d_prev; void *d_count, *d_prev_out, *d_m12;
+    if ((rc = io.in(ids, 8, &d_ids)) || (rc = io.in(prev_xy, (size_t)n1 * 8, &d_prev)) || (rc = io.out(&count, 4, &d_count)) ||
+        (rc = io.out(prev_new.data(), (size_t)n1 * 8, &d_prev_out)) || (rc = io.out(matches12, (size_t)n1 * 4, &d_m12)))
+        return rc;
     WinParams P;
     memset(&P, 0, sizeof P);
     P.frames = ctx->d_frames; P.qsets = ctx->d_qsets;
-    P.frame_ids = d_ids; P.qset_ids = d_ids + 1;
-    P.prev_xy = d_prev; P.out = d_m12; P.counts = d_count;
+    P.frame_ids = (const int32_t *)d_ids; P.qset_ids = (const int32_t *)d_ids + 1;
+    P.prev_xy = (const float *)d_prev; P.prev_out = (float *)d_prev_out; P.out = (int32_t *)d_m12; P.counts = (int32_t *)d_count;
     P.th = 1.0f; P.ratio = ratio; P.dist_th = ORBM_TH_LOW; P.check_ori = check_ori; P.stride = n1; P.window = window;
     rc = launch_window(ctx, MODE_INIT, P, 1, std::max(n2, 1), n1, ctx->h_frames[frame2].n_levels);
     if (rc) return rc;
-    int32_t count = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(prev_xy, d_prev, (size_t)n1 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(matches12, d_m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = io.finish();
+    if (rc) return rc;
+    for (int i = 0; i < n1; i++)
+        if (matches12[i] >= 0) { prev_xy[2 * i] = prev_new[2 * (size_t)i]; prev_xy[2 * i + 1] = prev_new[2 * (size_t)i + 1]; }
     return count;
 }
 
