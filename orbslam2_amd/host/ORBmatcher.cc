@@ -54,7 +54,8 @@ struct ResEntry {
     uint64_t content = 0;        // hash of EVERY descriptor row and keypoint, taken at upload
     uint64_t mp_version = ~0ull; // value of the caller's map-point version counter when `flags` was last refreshed
     size_t fv_size = 0;          // FeatureVector nodes the device copy was built from (0: none yet)
-    vector<uint8_t> flags;       // mp_flags as last sent
+    vector<uint8_t> flags;       // mp_flags as last looked at
+    bool flags_stale = false;    // `flags` is newer than the device copy (they went along with a search instead: see Acquire)
     std::list<ResKey>::iterator lru;
 };
 struct ThreadCtx {
@@ -225,7 +226,11 @@ detail::ResKey KeyOf(bool kf, const FrameLike &F) {
 // id of the device copy in this thread's context; mp_flags brought up to date (they change between calls, the rest does
 // not: Frame.h:235-291 members are written once, by the constructor and ComputeBoW)
 template <class FrameLike, class Source>
-int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint *> &mps, bool with_fv) {
+int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint *> &mps, bool with_fv, const uint8_t **defer = nullptr) {
+    // defer (windowed searches into one frame, whose slot state changes between any two calls of a tracking thread): changed
+    // flags are not sent to the device copy in a call of their own (a copy and a synchronisation) but handed back, to travel
+    // with the search as its slot_flags; *defer stays null when the device copy is current
+    if (defer) *defer = nullptr;
     orbm_ctx *ctx = Ctx();
     detail::ThreadCtx &t = detail::Thread();
     const detail::ResKey key = KeyOf(kf, F);
@@ -262,22 +267,25 @@ int32_t Acquire(bool kf, const FrameLike &F, Source &src, const vector<MapPoint 
     // device are current and the O(N) sweep below (a mutex-guarded isBad() + Observations() per keypoint) is skipped
     const std::atomic<uint64_t> *vsrc = detail::g_mp_version.load(std::memory_order_acquire);
     uint64_t vnow = 0;
-    if (vsrc) {
-        vnow = vsrc->load(std::memory_order_acquire);
-        if (vnow == e.mp_version) return e.frame;
-    }
-    bool same = true;
     const int n = F.N;
-    for (int i = 0; i < n; i++) {
-        const uint8_t fl = i < (int)mps.size() ? MpFlags(mps[i]) : 0;
-        if (fl != e.flags[i]) { e.flags[i] = fl; same = false; }
+    bool same = true;
+    if (vsrc) vnow = vsrc->load(std::memory_order_acquire);
+    if (!vsrc || vnow != e.mp_version) {
+        for (int i = 0; i < n; i++) {
+            const uint8_t fl = i < (int)mps.size() ? MpFlags(mps[i]) : 0;
+            if (fl != e.flags[i]) { e.flags[i] = fl; same = false; }
+        }
+        if (vsrc) e.mp_version = vnow;  // read BEFORE the sweep: a change during it bumps the counter past this value
     }
-    if (!same && n > 0) Check(orbm_frame_set_mp_flags(ctx, e.frame, e.flags.data()), "orbm_frame_set_mp_flags");
-    if (vsrc) e.mp_version = vnow;      // read BEFORE the sweep: a change during it bumps the counter past this value
+    if ((!same || e.flags_stale) && n > 0) {
+        if (defer) { *defer = e.flags.data(); e.flags_stale = true; }
+        else { Check(orbm_frame_set_mp_flags(ctx, e.frame, e.flags.data()), "orbm_frame_set_mp_flags"); e.flags_stale = false; }
+    }
     return e.frame;
 }
 
 int32_t Resident(const Frame &F, bool with_fv = false) { return Acquire(false, F, F, F.mvpMapPoints, with_fv); }
+int32_t ResidentDeferFlags(const Frame &F, const uint8_t *&slot_flags) { return Acquire(false, F, F, F.mvpMapPoints, false, &slot_flags); }
 int32_t Resident(KeyFrame *pKF, bool with_fv = false) { return Acquire(true, *pKF, pKF, pKF->GetMapPointMatches(), with_fv); }
 int32_t Resident(KeyFrame *pKF, const vector<MapPoint *> &mps, bool with_fv) { return Acquire(true, *pKF, pKF, mps, with_fv); }
 
@@ -398,13 +406,14 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoin
         lvl[i] = pMP->mnTrackScaleLevel; vc[i] = pMP->mTrackViewCos;
         memcpy(&desc[(size_t)i * 32], pMP->GetDescriptor().ptr<uint8_t>(), 32);
     }
-    const int32_t fid = Resident(F);
+    const uint8_t *slot_flags = nullptr;
+    const int32_t fid = ResidentDeferFlags(F, slot_flags);
     orbm_proj_queries q;
     q.n = Q; q.desc = desc.data(); q.proj_x = px.data(); q.proj_y = py.data(); q.proj_xr = pxr.data();
     q.level = lvl.data(); q.view_cos = vc.data(); q.flags = flags.data();
     int32_t count = 0;
     vector<int32_t> owner(F.N, -1);
-    Check(orbm_search_proj_points_once(Ctx(), fid, &q, th, mfNNratio, nullptr, owner.data(), &count), "orbm_search_proj_points_once");
+    Check(orbm_search_proj_points_once(Ctx(), fid, &q, th, mfNNratio, slot_flags, owner.data(), &count), "orbm_search_proj_points_once");
     for (int idx = 0; idx < F.N; idx++)
         if (owner[idx] >= 0) F.mvpMapPoints[idx] = vpMapPoints[owner[idx]];   // :160
     return count;
@@ -619,9 +628,10 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         q.flags[i] = ORBM_Q_VALID | (pMP->Observations() > 0 ? ORBM_Q_OBS : 0);
         q.SetDesc(i, pMP->GetDescriptor());
     }
-    const int32_t fid = Resident(CurrentFrame);
+    const uint8_t *slot_flags = nullptr;
+    const int32_t fid = ResidentDeferFlags(CurrentFrame, slot_flags);
     vector<int32_t> owner;
-    const int n = q.Run(0, fid, CurrentFrame.N, TH_HIGH, mbCheckOrientation, true, true, nullptr, owner);
+    const int n = q.Run(0, fid, CurrentFrame.N, TH_HIGH, mbCheckOrientation, true, true, slot_flags, owner);
     for (int idx = 0; idx < CurrentFrame.N; idx++) {
         if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = LastFrame.mvpMapPoints[owner[idx]];   // :1906
         else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = static_cast<MapPoint *>(NULL);  // :1942
@@ -665,9 +675,10 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
         q.flags[i] = ORBM_Q_VALID | ORBM_Q_OBS;
         q.SetDesc((int)i, pMP->GetDescriptor());
     }
-    const int32_t fid = Resident(CurrentFrame);
+    const uint8_t *slot_flags = nullptr;
+    const int32_t fid = ResidentDeferFlags(CurrentFrame, slot_flags);
     vector<int32_t> owner;
-    const int n = q.Run(1, fid, CurrentFrame.N, ORBdist, mbCheckOrientation, false, true, nullptr, owner);
+    const int n = q.Run(1, fid, CurrentFrame.N, ORBdist, mbCheckOrientation, false, true, slot_flags, owner);
     for (int idx = 0; idx < CurrentFrame.N; idx++) {
         if (owner[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = vpMPs[owner[idx]];        // :2066
         else if (owner[idx] == -2) CurrentFrame.mvpMapPoints[idx] = NULL;               // :2115
