@@ -610,6 +610,31 @@ static void TestWindowOverloads() {
                 for (int r = 0; r < 20; r++) { Cur.mvpMapPoints = before; matcher.SearchByProjection(Cur, Last, 7.0f, false); }
                 printf("latency SearchByProjection(Cur, Last, th=7) %d points into %d kp, resident: %.3f ms per call\n", Last.N, Cur.N, (NowMs() - t0) / 20);
                 EXPECT(Cur.mvpMapPoints == after, "repeated SearchByProjection(Cur, Last) calls differ");
+                // The slots of the resident frame have changed since its flags went to the device (they now hold the matches of the
+                // call above): the changed flags travel with the next windowed search, and a search of another kind afterwards
+                // (SearchByBoW below, in TestBoW-style use) must find them on the device copy.  Expected: the oracle on `after`.
+                vector<uint8_t> slot(rc.n, 0);
+                for (int i = 0; i < rc.n; i++)
+                    if (MapPoint *p = Cur.mvpMapPoints[i]) slot[i] = ORBM_MP_PRESENT | (p->mbBad ? ORBM_MP_BAD : 0) | (p->nObs > 0 ? ORBM_MP_OBS : 0);
+                vector<int32_t> owner2(rc.n); uint64_t nc2;
+                const int want2 = orc_search_window(0, &vt, &wq, 100, ori, slot.data(), owner2.data(), &nc2);
+                const int cnt2 = matcher.SearchByProjection(Cur, Last, 7.0f, false);
+                int bad2 = 0;
+                for (int i = 0; i < rc.n; i++) bad2 += Cur.mvpMapPoints[i] != (owner2[i] >= 0 ? Last.mvpMapPoints[owner2[i]] : owner2[i] == -2 ? nullptr : after[i]);
+                EXPECT(cnt2 == want2 && bad2 == 0, "second SearchByProjection(Cur, Last) on the changed slots: count %d vs %d, %d slots differ", cnt2, want2, bad2);
+                // ... and the flags reach the device copy when a call that cannot carry them needs them
+                vector<uint8_t> slot3(rc.n, 0);
+                for (int i = 0; i < rc.n; i++)
+                    if (MapPoint *p = Cur.mvpMapPoints[i]) slot3[i] = ORBM_MP_PRESENT | (p->mbBad ? ORBM_MP_BAD : 0) | (p->nObs > 0 ? ORBM_MP_OBS : 0);
+                const vector<MapPoint *> before3 = Cur.mvpMapPoints;
+                vector<MapPoint *> few(Last.mvpMapPoints.begin(), Last.mvpMapPoints.begin() + 200);
+                vector<MapPoint *> fewValid;
+                for (MapPoint *p : few) if (p) { p->mbTrackInView = true; p->mTrackProjX = 100.f + (float)fewValid.size(); p->mTrackProjY = 100.f; p->mTrackProjXR = 90.f; p->mnTrackScaleLevel = 0; p->mTrackViewCos = 1.f; fewValid.push_back(p); }
+                const int a1 = matcher.SearchByProjection(Cur, fewValid, 3.0f);   // (deferred flags again)
+                Cur.mvpMapPoints = before3;
+                ORBmatcher::Evict(Cur);                            // a fresh upload sets the flags from the slots themselves
+                const int a2 = matcher.SearchByProjection(Cur, fewValid, 3.0f);
+                EXPECT(a1 == a2, "SearchByProjection(F, MapPoints) with travelling flags %d vs freshly uploaded flags %d", a1, a2);
             }
         } else if (mode == 1) {
             want = orc_search_window(1, &vt, &wq, 64, ori, nullptr, owner.data(), &nc);
