@@ -245,12 +245,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int ia = first_node + node_step * (kb + lane);
         uint32_t nA = 0, nB = 0, offA = 0, offB = 0;
         if (ia < A.n_nodes) {
-            const uint32_t node_id = A.fv_node[ia];
-            const int guess = min(ia, B.n_nodes - 1);        // two keyframes usually populate the same nodes: same index
-            const int ib = (guess >= 0 && B.fv_node[guess] == node_id) ? guess : find_node(B.fv_node, B.n_nodes, node_id);
+            // two keyframes usually populate the same nodes, so the node sits at the same index of both lists: its offsets are
+            // requested together with the two node ids (one round trip to memory instead of two) and read again only on a miss
+            const int guess = min(ia, B.n_nodes - 1);
+            const uint32_t node_id = A.fv_node[ia], a0 = A.fv_off[ia], a1 = A.fv_off[ia + 1];
+            uint32_t bn = ~node_id, b0 = 0, b1 = 0;
+            if (guess >= 0) { bn = B.fv_node[guess]; b0 = B.fv_off[guess]; b1 = B.fv_off[guess + 1]; }
+            int ib = guess;
+            if (bn != node_id) {
+                ib = find_node(B.fv_node, B.n_nodes, node_id);
+                if (ib >= 0) { b0 = B.fv_off[ib]; b1 = B.fv_off[ib + 1]; }
+            }
             if (ib >= 0) {
-                offA = A.fv_off[ia]; nA = A.fv_off[ia + 1] - offA;
-                offB = B.fv_off[ib]; nB = B.fv_off[ib + 1] - offB;
+                offA = a0; nA = a1 - a0;
+                offB = b0; nB = b1 - b0;
                 if (nB == 0) nA = 0;
             }
         }
