@@ -539,6 +539,9 @@ constexpr int FUSED_CHUNK = FUSED_THREADS - 64;   // queries per chunk: waves 1.
 constexpr int PEND_WORDS = 10;                    // pending entry: meta, the query's angle, eight candidate words
 constexpr int FPARK = 2;                          // survivors a lane parks (in registers) between two distance passes
 
+// a5 (fused_kernel<MODE_INIT>) keeps, beyond the index: per query of a chunk its position, window and result (16 B) and its
+// descriptor (32 B), and the frame's descriptors by stream position (32 B per keypoint) -- see the cooperative search there
+static size_t fused_init_extra_bytes(const CoarseCfg &c) { return (size_t)(FUSED_THREADS - 64) * 48 + (size_t)c.n_cap * 32; }
 static size_t fused_lds_bytes(const CoarseCfg &c, bool with_binmask) {
     const int total = c.base[c.nstruct];
     const size_t offn = (size_t)((total + 6) & ~1);
@@ -664,6 +667,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
     // (two 16-bit counters per word).  A query whose window touches no such block is finished without a walk.
     uint32_t *fblk = fbits + fwords;
     uint32_t *fcnt = fblk + 8 * 12;
+    // a5 only (see the cooperative search in the chunk loop)
+    float *s_qx = reinterpret_cast<float *>(fcnt + 8 * 96), *s_qy = s_qx + FUSED_CHUNK;
+    uint32_t *s_qwin = reinterpret_cast<uint32_t *>(s_qy + FUSED_CHUNK), *s_qres = s_qwin + FUSED_CHUNK;
+    v4u *s_qdesc = reinterpret_cast<v4u *>(s_qres + FUSED_CHUNK);
+    v4u *ldesc = s_qdesc + 2 * FUSED_CHUNK;
     int *hist = s_hist, *nmatch = s_hist + 32, *keep = s_hist + 33;
 #ifdef ORBM_DIAG
     if (trace && inst == 0 && tid == 0) trace[0] = wall_clock64();
@@ -764,6 +772,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
 
     }
     if (MODE == MODE_INIT) for (int i = tid; i < Q; i += FUSED_THREADS) out[i] = -1;     // vnMatches12 (:566)
+    if (MODE == MODE_INIT) {                                                             // the frame's descriptors, by stream position
+        const gptr<const v4u> gd = (gptr<const v4u>)F.desc;
+        for (int j = tid; j < 2 * T; j += FUSED_THREADS) {
+            const int kp = (int)(__float_as_uint(F.cell_rec[j >> 1].w) & 0xFFFFu);
+            ldesc[j] = gd[2 * kp + (j & 1)];
+        }
+    }
     if (tid < 36) s_hist[tid] = 0;
     if (tid < 3) s_any[tid] = 0;
     if (tid == 0) s_stamp_mem = 0;
@@ -1043,6 +1058,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
                 if (BY1 >= BY0 + 3) rows |= fr[3];
                 if (BY1 <= BY0 + 3 && !(rows & colmask)) more = false;
             }
+            if constexpr (MODE == MODE_INIT) {
+                // a5: the query only publishes its window and its descriptor; the waves search the chunk's queries together below
+                uint32_t win = 0xFFFFFFFFu;
+                if (more && lo == hi) {
+                    load_desc<MODE>(S, qi, q);
+                    s_qdesc[2 * tid_c] = q.d0; s_qdesc[2 * tid_c + 1] = q.d1;
+                    s_qx[tid_c] = q.x; s_qy[tid_c] = q.y;
+                    win = (uint32_t)x0 | ((uint32_t)x1 << 6) | ((uint32_t)y0 << 12) | ((uint32_t)y1 << 18) | ((uint32_t)st << 24) | ((uint32_t)hi << 27);
+                } else if (more) uncovered = true;
+                s_qwin[tid_c] = win;
+                if (uncovered) *redo_flag = 1;
+            } else {
             const int kk = s_k[st], sb = s_base[st];
             int X = (x0 >> kk) - 1;
             const int X1 = x1 >> kk;
@@ -1138,6 +1165,103 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
             // more candidates than this form has words for (or a level range the index does not cover: cannot happen with the
             // launch rules): the instance is flagged and searched again, whole, by the general kernel that follows this one
             if (uncovered || ncand > tcap + NW) { *redo_flag = 1; ncand = min(ncand, tcap + NW); }
+            }
+        }
+        if constexpr (MODE == MODE_INIT) {
+            // ---- a5: cooperative search.  Its valid queries are the level-0 keypoints of frame 1, a few hundred of them side by
+            // side in the query order (a handful of waves), each with some thirty candidates in a 2 x 100 px window and a
+            // distance to compute for every one (the slot test `vMatchedDistance[i2] <= dist`, :608, needs it): one query per
+            // lane made that a chain of thirty dependent steps on four waves while eleven idled.  Here wave w takes the
+            // queries w - 1, w + 14, ... of the chunk one after the other and spreads each one's candidates over its lanes:
+            // the runs of the window's coarse columns are laid end to end (a prefix sum over the columns, one per lane), lane
+            // l takes entry l, applies the gates, computes its distance against descriptors held in LDS, and the words of
+            // the survivors go, packed, to the query's tail in global scratch (ALL words: the owner reads its first eight
+            // back).  The order of the words does not matter: they carry the reference's ranking themselves.
+            lds_barrier();                                  // (I1) the chunk's windows and descriptors are in LDS
+            if (wave > 0) {
+                const float r = (float)P.window;
+                for (int t = 0; t < 64; t++) {
+                    const int pos = (wave - 1) + 15 * t;
+                    const uint32_t win = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_qwin[pos]);
+                    if (win == 0xFFFFFFFFu) continue;
+                    const int x0 = (int)(win & 63u), x1 = (int)((win >> 6) & 63u), y0 = (int)((win >> 12) & 63u), y1 = (int)((win >> 18) & 63u);
+                    const int st = (int)((win >> 24) & 7u), lv = (int)((win >> 27) & 15u);
+                    const float qx = s_qx[pos], qy = s_qy[pos];
+                    const v4u q0 = s_qdesc[2 * pos], q1 = s_qdesc[2 * pos + 1];
+                    const uint32_t qd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    const int kk = s_k[st], sb = s_base[st];
+                    const int X0 = x0 >> kk, ncol = (x1 >> kk) - X0 + 1;
+                    uint32_t jc = 0, len = 0;
+                    if (lane < ncol) {
+                        const int b = sb + (X0 + lane) * ORBM_GRID_ROWS;
+                        jc = c_off[b + y0 + 1];
+                        len = (uint32_t)c_off[b + y1 + 2] - jc;
+                    }
+                    uint32_t incl = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t up = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += up;
+                    }
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t *tailq = tail_scratch + ((size_t)(inst * 2 + (c & 1)) * FUSED_CHUNK + pos) * tcap;
+                    uint32_t cnt = 0, md = 0xFFFFu;
+                    for (uint32_t eb = 0; eb < total; eb += 64) {
+                        const uint32_t l = eb + (uint32_t)lane;
+                        const bool have = l < total;
+                        uint32_t idx = 0;
+                        for (int cc2 = 0; cc2 < ncol; cc2++) {
+                            const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)incl, cc2), lc = (uint32_t)__builtin_amdgcn_readlane((int)len, cc2);
+                            const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)jc, cc2);
+                            if (l < ic && l >= ic - lc) idx = j0 + (l - (ic - lc));
+                        }
+                        bool keep = false;
+                        uint32_t x = 0, dist = 0xFFFFu;
+                        if (have) {
+                            const uint32_t jcur = c_lst[idx];
+                            const v4f rc = c_rec[jcur];
+                            const uint32_t w = __float_as_uint(rc.w);
+                            const int oct = (int)((w >> 13) & 15u), cx = (int)((w >> 17) & 63u);
+                            const int pass = (int)(cx >= x0) & (int)(cx <= x1) & (int)(oct == lv) &
+                                             (int)(fabsf(__fsub_rn(rc.x, qx)) < r) & (int)(fabsf(__fsub_rn(rc.y, qy)) < r);
+                            if (pass) {
+                                const v4u dlo = ldesc[2 * jcur], dhi = ldesc[2 * jcur + 1];
+                                const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
+                                dist = hamming256(qd, cd);
+                                keep = !((int)state[jcur] <= (int)dist);                      // :608, with the distance
+                                x = (dist << 17) | (jcur << 4) | (uint32_t)oct;
+                            }
+                        }
+                        const unsigned long long km = __ballot(keep);
+                        if (keep) {
+                            const uint32_t pp = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                            if (pp < (uint32_t)tcap) tailq[pp] = x;
+                            md = min(md, dist);
+                        }
+                        cnt += (uint32_t)__popcll(km);
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) md = min(md, (uint32_t)__shfl_xor((int)md, off, 64));
+                    if (cnt > (uint32_t)tcap) { *redo_flag = 1; cnt = (uint32_t)tcap; }
+                    if (lane == 0) s_qres[pos] = cnt | (md << 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the tail words are global memory
+            }
+            lds_barrier();                                  // (I2) every query's words and count are there
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (wave > 0 && s_qwin[tid_c] != 0xFFFFFFFFu) {
+                const uint32_t res = s_qres[tid_c];
+                ncand = (int)(res & 0xFFFFu); mind = res >> 16;
+                if (ncand > 0) {
+                    const gptr<const v4u> tq = (gptr<const v4u>)in_global(mytail_w);
+                    const v4u a = tq[0];
+                    kw[0] = a.x; kw[1] = ncand > 1 ? a.y : W_INVALID; kw[2] = ncand > 2 ? a.z : W_INVALID; kw[3] = ncand > 3 ? a.w : W_INVALID;
+                    if (ncand > 4) {
+                        const v4u b4 = tq[1];
+                        kw[4] = b4.x; kw[5] = ncand > 5 ? b4.y : W_INVALID; kw[6] = ncand > 6 ? b4.z : W_INVALID; kw[7] = ncand > 7 ? b4.w : W_INVALID;
+                    }
+                }
+            }
         }
         const bool live = wave > 0 && ncand > 0 && (int)mind <= thr;
         const unsigned long long lmask = __ballot(live);
@@ -1164,7 +1288,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
         // no free slot is left in the frame and nothing is pending: every remaining query would skip every candidate
         // (ORBmatcher.cc:113-115): the search is over
         if (L == 0 && s_free_total == 0) break;
-        const gptr<const uint32_t> mytail_r = in_global(mytail_w);
+        // (a5: the tail holds ALL of a query's words, the code below expects the ninth at its start)
+        const gptr<const uint32_t> mytail_r = in_global(mytail_w) + (MODE == MODE_INIT ? NW : 0);
         if (L > NARROW_MAX) {
             // ---- many live queries (the first chunks of an instance): every searching lane keeps its own query and the whole
             // workgroup goes through the rounds together, claim priority = position in the chunk
@@ -1207,7 +1332,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(WinParams P, Coars
             }
             const int t_c = (int)(meta & 1023u);
             const int ncand2 = mine ? (int)((meta >> 10) & 0xFFFFu) : 0;
-            const gptr<const uint32_t> mytail = in_global(tail_scratch) + ((size_t)(inst * 2 + (c & 1)) * FUSED_CHUNK + t_c) * tcap;
+            const gptr<const uint32_t> mytail = in_global(tail_scratch) + ((size_t)(inst * 2 + (c & 1)) * FUSED_CHUNK + t_c) * tcap + (MODE == MODE_INIT ? NW : 0);
             if (__any(mine && ncand2 > NW)) {
                 if (mine && ncand2 > NW) load_tail(cc, mytail, ncand2 - NW);
             }
@@ -1882,7 +2007,7 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
     // (keeping the frame's descriptors in LDS as well was measured no faster, for a6 / a11 batches -- the search of the first
     // chunks is bound by instruction issue, not by the candidate gathers -- and for a5 alone, whose few hundred valid queries
     // walk some thirty candidates each, one after the other: 127 against 129 us per call; the 32 B per keypoint stay free)
-    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK);
+    const size_t fused_lds = fused_lds_bytes(cfg, BINMASK) + (MODE == MODE_INIT ? fused_init_extra_bytes(cfg) : 0);
     const bool fused_fits = index_ok && fused_lds <= FUSED_LDS_MAX && max_q > 0;
     if (fused_fits && g_win_variant != 1 && g_win_variant != 2 && g_win_variant != 4 &&
         (g_win_variant == 3 || MODE == MODE_INIT || n_inst >= g_win_fused_min_inst || max_q <= g_win_fused_max_q)) {

@@ -88,3 +88,36 @@ def test_no_device_memory_growth_over_upload_match_free_cycles(ctx, orc):
     free1, _ = torch.cuda.mem_get_info()
     ctx.free_vocabulary(vid)
     assert free0 - free1 < 300 * 1024 * 1024, (free0, free1)
+
+
+def test_round3_entry_points_refuse_bad_arguments(ctx, orc):
+    """orbm_search_*_once, orbm_allpairs: bad arguments are errors with a message, empty inputs are not, and the context
+    works afterwards."""
+    from orbslam2_amd.matcher import Context, OrbmError
+    f, q = synth.proj_instance(seed=16, n=300, n_queries=200)
+    fw, qw = synth.window_instance(17, 0, n=300, n_queries=150, th=7.0, stereo=True)
+    ids = ctx.upload_frames([f, fw])
+    bad_calls = [
+        lambda: ctx.search_proj_points_once(9999, q, 3.0, 0.8, 300),                      # unknown frame
+        lambda: ctx.search_window_once(5, ids[1], qw, 100, True, 300),                    # mode out of range
+        lambda: ctx.search_window_once(0, -3, qw, 100, True, 300),
+        lambda: Context.allpairs_multi([ctx], [ids], 7, [0], [1], None, 0.75, 50, True, 300, 20, 64),      # kind out of range
+    ]
+    for k, call in enumerate(bad_calls):
+        with pytest.raises(OrbmError) as e:
+            call()
+        assert str(e.value), k
+    # an empty query set is a search with no matches, not an error
+    import copy
+    q0 = copy.copy(q)
+    for name in ("desc", "proj_x", "proj_y", "proj_xr", "level", "view_cos"):
+        setattr(q0, name, getattr(q, name)[:0])
+    if hasattr(q0, "flags") and q0.flags is not None:
+        q0.flags = q0.flags[:0]
+    cnt, owner = ctx.search_proj_points_once(ids[0], q0, 3.0, 0.8, 300)
+    assert cnt == 0 and (owner == -1).all()
+    # ... and the context still gives the oracle's answer
+    cnt, owner = ctx.search_proj_points_once(ids[0], q, 3.0, 0.8, 300)
+    wc, wo, _ = orc.search_proj_points(f, q, 3.0, 0.8)
+    assert cnt == wc and np.array_equal(owner[:f.n], wo)
+    ctx.free_frames(ids)
