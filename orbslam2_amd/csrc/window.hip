@@ -258,7 +258,8 @@ __device__ __forceinline__ int word_tail(uint32_t head2, uint32_t head3) {
 
 template <int MODE>
 __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, int waves_per_inst, int wgs_per_inst,
-                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt, int cost_exact, int desc_lds) {
+                                                                  v4u *head_out, uint32_t *tail_out, int tcap, CoarseCfg cfg, int groups, int qt, int cost_exact, int desc_lds,
+                                                                  int coop) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ int s_k[8], s_base[9];
     __shared__ uint32_t s_part[COLLECT_THREADS / 64];
@@ -343,6 +344,142 @@ __global__ __launch_bounds__(COLLECT_THREADS) void collect_kernel(WinParams P, i
     const bool stereo_gate = has_stereo_gate<MODE>(S);
     const gptr<const v4u> gdesc = (gptr<const v4u>)F.desc;
     const float min_x = F.min_x, min_y = F.min_y, inv_w = F.inv_w, inv_h = F.inv_h;
+    if (coop) {
+        // ---- few queries in the whole launch (one tracking call): `coop` queries per workgroup, one or two per WAVE, and a
+        // wave spreads a query's candidates over its lanes -- the runs of the window's coarse columns laid end to end (a
+        // prefix sum over the columns, one per lane), lane l takes entry l: gates, distance, word.  One query per lane made
+        // a wave walk its longest window, fifteen to twenty-five dependent steps, while the other fifteen waves of the
+        // workgroup had nothing to do (13 of the kernel's 19 us for a 1500-query call).  The four smallest words are picked
+        // with four wave minima; more than 64 survivors (or a level range the index does not cover): the query is
+        // flagged and the claims kernel walks its window itself, as for any query with more candidates than the tail holds.
+        const int per_wave = coop / (COLLECT_THREADS / 64), nq_inst = waves_per_inst * 64;
+        uint32_t *wscr = reinterpret_cast<uint32_t *>(l_cc) + wave * 64;
+        Query qs[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int qi = part * coop + wave * per_wave + u;
+            qs[u] = load_params<MODE>(P, F, S, (u < per_wave && qi < nq_inst) ? qi : S.Q);
+            if (qs[u].valid) load_desc<MODE>(S, qi, qs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int qi = part * coop + wave * per_wave + u;
+            if (u >= per_wave || qi >= nq_inst) continue;
+            const Query &q = qs[u];
+            uint32_t k0 = W_INVALID, k1 = W_INVALID, k2 = W_INVALID, k3 = W_INVALID;
+            bool rewalk = false;
+            int nsel = 0;
+            uint32_t *mytail = tail_out + ((size_t)inst * ((size_t)waves_per_inst * 64) + qi) * tcap;
+            const float xr = __fsub_rn(q.x, min_x), yr = __fsub_rn(q.y, min_y), r = q.r;
+            const int x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(xr, r), inv_w)));
+            const int x1 = min(ORBM_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(xr, r), inv_w)));
+            const int y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(yr, r), inv_h)));
+            const int y1 = min(ORBM_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(yr, r), inv_h)));
+            int lo = -1, hi = 255;
+            if (MODE == MODE_SIM3) { lo = q.minL; hi = q.maxL; }
+            else if (q.minL > 0 || q.maxL >= 0) { lo = q.minL; if (q.maxL >= 0) hi = q.maxL; }
+            const bool open_win = q.valid && x0 < ORBM_GRID_COLS && x1 >= 0 && y0 < ORBM_GRID_ROWS && y1 >= 0 && x1 >= x0 && y1 >= y0;
+            if (__builtin_amdgcn_readfirstlane((int)open_win)) {
+                int st = 0;
+                bool covered = !pairs;
+                if (pairs && hi <= 7 && hi >= 0 && hi - lo <= 1) { st = hi; covered = true; }
+                st = __builtin_amdgcn_readfirstlane(st);
+                if (!__builtin_amdgcn_readfirstlane((int)covered)) rewalk = true;
+                else {
+                    const uint32_t qd[8] = {q.d0.x, q.d0.y, q.d0.z, q.d0.w, q.d1.x, q.d1.y, q.d1.z, q.d1.w};
+                    const int kk = s_k[st], sb = s_base[st];
+                    const int X0 = __builtin_amdgcn_readfirstlane(x0 >> kk), ncol = __builtin_amdgcn_readfirstlane((x1 >> kk) - (x0 >> kk) + 1);
+                    uint32_t jc = 0, len = 0;
+                    if (lane < ncol) {
+                        const int b = sb + (X0 + lane) * ORBM_GRID_ROWS;
+                        jc = c_off[b + y0 + 1];
+                        len = (uint32_t)c_off[b + y1 + 2] - jc;
+                    }
+                    uint32_t incl = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t up = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += up;
+                    }
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    auto candidate = [&](uint32_t l) -> uint32_t {
+                        if (l >= total) return W_INVALID;
+                        uint32_t idx = 0;
+                        for (int c2 = 0; c2 < ncol; c2++) {
+                            const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)incl, c2), lc = (uint32_t)__builtin_amdgcn_readlane((int)len, c2);
+                            const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)jc, c2);
+                            if (l < ic && l >= ic - lc) idx = j0 + (l - (ic - lc));
+                        }
+                        const uint32_t jcur = c_lst[idx];
+                        const v4f rc = c_rec[jcur];
+                        const uint32_t w = __float_as_uint(rc.w);
+                        const int oct = (int)((w >> 13) & 15u), cx = (int)(w >> 17);
+                        int pass = (int)(cx >= x0) & (int)(cx <= x1) & (int)(oct >= lo) & (int)(oct <= hi) &
+                                   (int)(fabsf(__fsub_rn(rc.x, q.x)) < r) & (int)(fabsf(__fsub_rn(rc.y, q.y)) < r);
+                        if (stereo_gate) pass &= 1 ^ ((int)(rc.z > 0) & (int)(fabsf(__fsub_rn(q.xr, rc.z)) > r));   // :117-122 / :1883-1891
+                        if (!pass) return W_INVALID;
+                        v4u dlo, dhi;
+                        if (desc_lds) { dlo = l_desc[2 * jcur]; dhi = l_desc[2 * jcur + 1]; }
+                        else { const int kp = (int)F.cell_idx[jcur]; dlo = gdesc[2 * kp]; dhi = gdesc[2 * kp + 1]; }
+                        const uint32_t cd[8] = {dlo.x, dlo.y, dlo.z, dlo.w, dhi.x, dhi.y, dhi.z, dhi.w};
+                        return (hamming256(qd, cd) << 17) | (jcur << 4) | (uint32_t)oct;
+                    };
+                    uint32_t word = W_INVALID;
+                    if (total <= 64) word = candidate((uint32_t)lane);
+                    else {
+                        // (wide windows over crowded cells: the survivors of every pass are gathered in LDS first)
+                        int nsurv = 0;
+                        for (uint32_t eb = 0; eb < total; eb += 64) {
+                            const uint32_t w2 = candidate(eb + (uint32_t)lane);
+                            const unsigned long long sm = __ballot(w2 != W_INVALID);
+                            if (w2 != W_INVALID) {
+                                const int pp = nsurv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                                if (pp < 64) wscr[pp] = w2;
+                            }
+                            nsurv += (int)__popcll(sm);
+                        }
+                        if (nsurv > 64) rewalk = true;
+                        else {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < nsurv) word = wscr[lane];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    if (!rewalk) {
+                        nsel = (int)__popcll(__ballot(word != W_INVALID));
+                        uint32_t rest = word, kk4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            uint32_t m = rest;
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
+                            kk4[i] = m;
+                            if (rest == m) rest = W_INVALID;          // (words are distinct: they carry the stream position)
+                        }
+                        k0 = kk4[0]; k1 = kk4[1]; k2 = kk4[2]; k3 = kk4[3];
+                        const unsigned long long rm = __ballot(rest != W_INVALID);
+                        if (rest != W_INVALID) {
+                            const int pp = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                            if (pp < tcap) mytail[pp] = rest;
+                        }
+                        if (nsel > tcap + 4) rewalk = true;
+                    }
+                }
+            }
+            if (lane == 0) {
+                if (nsel > 4) {
+                    const uint32_t tc = (uint32_t)(nsel - 4);
+                    k3 |= (tc & 15u) << 28; k2 |= (tc >> 4) << 28;
+                }
+                if (rewalk) { k2 = W_FLAGS; k3 = W_FLAGS; }              // count 255: live, re-walked by the claims kernel
+                head_out[(size_t)inst * ((size_t)waves_per_inst * 64) + qi] = v4u{k0, k1, k2, k3};
+            }
+        }
+        WIN_STAMP(4); WIN_STAMP(5);
+        return;
+    }
     // queries sorted together: `groups` rows of 64 per wave (2; 1 when the launch has few instances, so that one instance
     // spreads over more workgroups)
     // qt = queries per row of a super-chunk (a multiple of 64, COLLECT_THREADS unless the launch has too few queries to give
@@ -1867,8 +2004,10 @@ __global__ void window_kernel(WinParams P, int waves_per_inst, const v4u *head_i
         }
     } else {
         // keypoints outside the grid (no stream position) are never candidates: -1
-        for (int i = tid; i < n; i += nthr) out[i] = -1;
-        __syncthreads();
+        if (n_slots != n) {
+            for (int i = tid; i < n; i += nthr) out[i] = -1;
+            __syncthreads();
+        }
         for (int i = tid; i < n_slots; i += nthr) out[F.cell_idx[i]] = owner[i];
     }
     if (tid == 0) P.counts[inst] = *nmatch;
@@ -1980,6 +2119,7 @@ int g_win_variant = 0;
 // is faster fused from a few dozen instances on: 256 x 50k queries 0.24 against 0.88 ms)
 int g_win_fused_min_inst = 48;     // fused from this many instances per call ...
 int g_win_fused_max_q = 0;         // ... or when no query set of the call is larger than this (0: never by size)
+int g_win_coop = 1;                // split form: calls with few queries spread every query's candidates over a wave's lanes (test knob)
 int g_win_cost_exact = 1;   // cost classes of collect_kernel: 1 = the walk's exact trip count, 0 = window area (A/B knob)
 
 template <int MODE>
@@ -2111,8 +2251,15 @@ int launch_mode(orbm_ctx *ctx, const WinParams &P, int n_inst, int max_n, int ma
                 qt = (int)std::min<long long>(COLLECT_THREADS, std::max<long long>(64, (per_wg + 63) / 64 * 64));
                 wgs_per_inst = std::max(1, (waves_per_inst * 64 + qt - 1) / qt);
             }
+            // a call with few queries in all (a tracking frame): one or two queries per WAVE, a query's candidates over the lanes
+            int coop = 0;
+            const long long total_q = (long long)ni * waves_per_inst * 64;
+            if (g_win_coop && MODE != MODE_INIT && total_q <= 2LL * WAVES * wg_target) {
+                coop = total_q <= (long long)WAVES * wg_target ? WAVES : 2 * WAVES;
+                wgs_per_inst = (waves_per_inst * 64 + coop - 1) / coop;
+            }
             hipLaunchKernelGGL((collect_kernel<MODE>), dim3((unsigned)(ni * wgs_per_inst)), dim3(COLLECT_THREADS), lds, ctx->stream, R,
-                               waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact, desc_lds ? 1 : 0);
+                               waves_per_inst, wgs_per_inst, head, tail, tcap, cfg, groups, qt, g_win_cost_exact, desc_lds ? 1 : 0, coop);
             HIPCHK(ctx, hipGetLastError());
             rc = launch_claims<MODE, false, true>(ctx, R, ni, max_n, threads, waves_per_inst, head, tail, tcap);
             if (rc) return rc;
@@ -2204,6 +2351,7 @@ extern "C" void orbm__window_stamps(unsigned long long *out, int clear) {
 #endif
 extern "C" void orbm__window_variant(int v) { g_win_variant = v; }
 extern "C" void orbm__window_fused_rule(int min_inst, int max_q) { g_win_fused_min_inst = min_inst; g_win_fused_max_q = max_q; }
+extern "C" void orbm__window_coop(int on) { g_win_coop = on; }
 #ifdef ORBM_DIAG
 // phase-timing diagnostics of collect_kernel (bits 1-3 switch phases off: wrong results); only in `make diag` builds
 extern "C" void orbm__window_cost_exact(int v) { g_win_cost_exact = v; }

@@ -183,7 +183,7 @@ def test_release_library_exports_no_result_changing_knob():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     knobs = {l.split()[-1] for l in out.splitlines() if " orbm__" in l}
     assert knobs <= {"orbm__bf2nn_variant", "orbm__bow_variant", "orbm__bow_split_below", "orbm__bowm_wgs", "orbm__stereo_variant",
-                     "orbm__vocab_variant", "orbm__window_variant", "orbm__window_fused_rule"}, knobs
+                     "orbm__vocab_variant", "orbm__window_variant", "orbm__window_fused_rule", "orbm__window_coop"}, knobs
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"ORBM_MFMA_DIAG" not in blob
 

@@ -367,15 +367,17 @@ def test_search_init_steals(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 40])
 def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
     """The windowed searches have four forms (0 = chosen by batch shape; 3 = fused: one launch, a workgroup per instance searches
-    and settles claims; 4 = split: collect + claims kernels; 1 = single kernel with the frame in LDS; 2 = single kernel reading
+    and settles claims; 4 = split: collect + claims kernels -- with few queries in the call a query's candidates are spread
+    over a wave's lanes, 40 = split without that; 1 = single kernel with the frame in LDS; 2 = single kernel reading
     global memory; frames above 2200 keypoints never use LDS staging): same results."""
     from orbslam2_amd import _lib
     L = _lib.load()
     try:
-        L.orbm__window_variant(variant)
+        L.orbm__window_variant(4 if variant == 40 else variant)
+        L.orbm__window_coop(0 if variant == 40 else 1)
         for seed, n, nq, th, stereo in ((901, 3000, 8000, 3.0, False), (902, 800, 5000, 5.0, True), (904, 2000, 3000, 1.0, False),
                                          (905, 2000, 3000, 8.0, True)):   # th 8: more candidates than a row holds
             f, q = synth.proj_instance(seed=seed, n=n, n_queries=nq, claimed_frac=0.1, obs_frac=0.7, stereo=stereo)
@@ -394,6 +396,7 @@ def test_window_kernel_variants_are_all_exact(ctx, orc, variant):
                 ctx.free_frames(fid); ctx.free_queries(qid)
     finally:
         L.orbm__window_variant(0)
+        L.orbm__window_coop(1)
 
 
 @pytest.mark.parametrize("n", [2040, 2100, 2124, 2160, 3300, 4900, 5300, 6500, 8100])
