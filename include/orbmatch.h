@@ -121,6 +121,14 @@ void orbm_destroy(orbm_ctx *ctx);
 const char *orbm_last_error(const orbm_ctx *ctx);
 /* adopt a caller's hipStream_t (NULL is the HIP null stream); (void*)-1 returns to the context's own stream */
 int orbm_set_stream(orbm_ctx *ctx, void *hip_stream);
+/* Measurement (no counterpart in the reference; bench.py's roofline figure): after orbm_kernel_timing(ctx, n) the library
+ * records a pair of HIP events on the context's stream around the matching kernel of each of the next n brute-force
+ * launches (orbm_bf2nn_batch, orbm_allpairs_batch kind 0) -- the kernel alone, not the call's memsets or the record
+ * compaction -- without synchronising anything.  orbm_kernel_times synchronises the stream, writes the elapsed
+ * milliseconds of the recorded launches (at most cap) and returns how many were recorded; recording starts over.
+ * orbm_kernel_timing(ctx, 0) switches it off.  Creates and destroys events: not for the allocation-free callers. */
+int orbm_kernel_timing(orbm_ctx *ctx, int max_launches);
+int orbm_kernel_times(orbm_ctx *ctx, float *ms, int cap);
 int orbm_synchronize(orbm_ctx *ctx);
 int orbm_device_info(orbm_ctx *ctx, int32_t *n_cu, int32_t *clock_khz, char *name, int name_len);
 

@@ -14,6 +14,7 @@ if os.environ.get("ORBM_DIAG_LIB") == "1":
 # every symbol include/orbmatch.h declares
 SYMBOLS = [
     "orbm_create", "orbm_destroy", "orbm_last_error", "orbm_set_stream", "orbm_synchronize", "orbm_device_info",
+    "orbm_kernel_timing", "orbm_kernel_times",
     "orbm_frames_upload", "orbm_frames_free", "orbm_frame_set_mp_flags", "orbm_frame_grid_download",
     "orbm_proj_queries_upload", "orbm_win_queries_upload", "orbm_queries_free",
     "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_stereo_match_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
@@ -46,6 +47,8 @@ def load():
     L.orbm_last_error.argtypes = [vp]
     L.orbm_set_stream.argtypes = [vp, vp]
     L.orbm_synchronize.argtypes = [vp]
+    L.orbm_kernel_timing.argtypes = [vp, C.c_int]
+    L.orbm_kernel_times.argtypes = [vp, vp, C.c_int]
     L.orbm_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_int]
     L.orbm_frames_upload.argtypes = [vp, C.c_int, C.POINTER(CFrameView), vp]
     L.orbm_frames_free.argtypes = [vp, C.c_int, vp]

@@ -782,6 +782,8 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
 #define MF4R_LAUNCH(WD, NTT, ...)                                                                                                \
         hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT, ##__VA_ARGS__>), dim3((unsigned)gridr), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
+        hipEvent_t *tev = orbm_timing_slot(ctx);           // orbm_kernel_timing: this launch alone, on its stream
+        if (tev) HIPCHK(ctx, hipEventRecord(tev[0], ctx->stream));
         if (variant == 13) { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }     // A/B: without s_setprio
         else if (variant == 16) { if (best_d || second_d) MF4R_LAUNCH(true, 4, 3); else MF4R_LAUNCH(false, 4, 3); }
 #ifdef ORBM_DIAG
@@ -794,6 +796,7 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }
 #undef MF4R_LAUNCH
         HIPCHK(ctx, hipGetLastError());
+        if (tev) HIPCHK(ctx, hipEventRecord(tev[1], ctx->stream));
         return io.finish();
     }
     if (variant == 9) {                 // MFMA form: +-1 int8 images of the frames, built on first use

@@ -298,6 +298,11 @@ __global__ __launch_bounds__(256) void popcount_peak_kernel(int iters, uint32_t 
     sink[t] = acc[0] + acc[1] + acc[2] + acc[3];
 }
 
+hipEvent_t *orbm_timing_slot(orbm_ctx *ctx) {
+    if ((size_t)(2 * ctx->tev_used + 2) > ctx->tev.size()) return nullptr;
+    return &ctx->tev[2 * (size_t)ctx->tev_used++];
+}
+
 extern "C" {
 
 orbm_ctx *orbm_create(int device) {
@@ -331,10 +336,38 @@ orbm_ctx *orbm_create(int device) {
     return ctx;
 }
 
+int orbm_kernel_timing(orbm_ctx *ctx, int max_launches) {
+    if (!ctx) return ORBM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
+    ctx->tev.clear(); ctx->tev_used = 0;
+    if (max_launches <= 0) return ORBM_OK;
+    if (max_launches > 65536) return orbm_fail(ctx, ORBM_ELIMIT, "kernel_timing: at most 65536 launches");
+    for (int i = 0; i < 2 * max_launches; i++) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->tev.push_back(e);
+    }
+    return ORBM_OK;
+}
+
+int orbm_kernel_times(orbm_ctx *ctx, float *ms, int cap) {
+    if (!ctx || (cap > 0 && !ms)) return ORBM_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = std::min(ctx->tev_used, cap);
+    for (int i = 0; i < n; i++) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->tev[2 * i], ctx->tev[2 * i + 1]));
+    const int used = ctx->tev_used;
+    ctx->tev_used = 0;
+    return used;
+}
+
 void orbm_destroy(orbm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     for (auto &a : ctx->arenas) if (a.base) (void)hipFree(a.base);
     for (auto &a : ctx->arena_pool) if (a.base) (void)hipFree(a.base);
     for (auto &v : ctx->vocabs) if (v.arena.base) (void)hipFree(v.arena.base);

@@ -88,6 +88,9 @@ struct orbm_ctx {
     hipStream_t own_stream = nullptr;
     std::string err;
     hipDeviceProp_t prop;
+    // measurement (orbm_kernel_timing): event pairs around the dominant kernel of the brute-force search
+    std::vector<hipEvent_t> tev;     // 2 per launch
+    int tev_used = 0;
     // frame table
     std::vector<FrameDev> h_frames;
     std::vector<int> frame_arena;      // arena index per slot, -1 = free slot
@@ -145,6 +148,7 @@ void orbm_arena_release(orbm_ctx *ctx, Arena &a);                // to the pool 
 int orbm_ws_reserve(orbm_ctx *ctx, size_t bytes);    // I/O staging
 void *orbm_pin_up(orbm_ctx *ctx, size_t bytes);      // pinned upload staging of at least `bytes`, or null (too large / failed)
 int orbm_ws2_reserve(orbm_ctx *ctx, size_t bytes);   // kernel scratch
+hipEvent_t *orbm_timing_slot(orbm_ctx *ctx);         // next event pair of orbm_kernel_timing, or null
 int orbm_check_frames(orbm_ctx *ctx, int n, const int32_t *ids, const char *what);
 int orbm_ensure_image(orbm_ctx *ctx, int bits, int n, const int32_t *ids);   // bits = 8 (desc8), 4 (desc4) or 5 (descfv, raw rows in FeatureVector order); ids == nullptr: every live frame
 void orbm_drop_fv_image(orbm_ctx *ctx, int32_t id);                          // host side of "the FeatureVector of frame id was rebuilt" (the device entry is cleared by the rebuilding kernel)

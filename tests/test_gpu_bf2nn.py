@@ -305,3 +305,23 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_kernel_timing_records_the_matching_kernel(ctx, orc):
+    """orbm_kernel_timing / orbm_kernel_times (bench.py's roofline figure): one event pair per brute-force launch, read back after
+    a synchronisation; results are untouched and the recording stops at the capacity asked for."""
+    import ctypes as C
+    kfs = synth.keyframe_pool(seed=77, n_kf=2, n=500)
+    ids = ctx.upload_frames(kfs)
+    L = ctx._L
+    assert L.orbm_kernel_timing(ctx._h, 2) == 0
+    for _ in range(3):                                       # the third launch finds no event pair left: not recorded, not an error
+        c, m, bd, sd = ctx.bf2nn([ids[0]], [ids[1]], 0.75, 50, stride=500)
+    wc, wm, wb, ws, _ = orc.bf2nn(kfs[0], kfs[1], 0.75, 50)
+    assert c[0] == wc and np.array_equal(m[0], wm)
+    buf = (C.c_float * 4)()
+    assert L.orbm_kernel_times(ctx._h, buf, 4) == 2
+    assert 0.0 < buf[0] < 50.0 and 0.0 < buf[1] < 50.0
+    assert L.orbm_kernel_times(ctx._h, buf, 4) == 0          # reading starts the recording over
+    assert L.orbm_kernel_timing(ctx._h, 0) == 0
+    ctx.free_frames(ids)
