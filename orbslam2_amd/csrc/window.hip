@@ -24,6 +24,20 @@
 // Slots only ever become blocked and a post means "a lower query's outcome may depend on this slot staying free", so
 // the best / second-best pair of a final query is the one the sequential loop would have found; the lowest
 // unresolved query is always final, so every round makes progress.  Typical inputs need 2-4 rounds per chunk.
+// (A query whose ratio test passes on distances now names and waits for its best slot only: the second-best can only get
+// worse, see `second_matters`.)
+//
+// Three forms of that, chosen by launch_mode() from the shape of the call, all returning the same bits:
+//   fused_kernel      one launch, one workgroup per instance, for batches (>= 48 instances) and for a5.  The search tests the
+//                     slot BEFORE the descriptor, as the reference's own loop does, through free bitmaps over a per-launch LDS
+//                     index; claims of a chunk are settled by all waves together or by wave 0 while the next chunk is searched.
+//                     a5 searches cooperatively (a query's candidates over a wave's lanes).
+//   collect_kernel +  the split form, for a call with one or a few instances: the search spread over the whole chip (every
+//   window_kernel<PRE>  workgroup builds the LDS index, then one query per lane -- or, with few queries in the call, one or two
+//                     queries per WAVE and a query's candidates over the lanes), then one workgroup per instance settles the claims
+//                     on the candidate words the search left in global scratch.
+//   window_kernel     the single-kernel forms (walk + rounds in one workgroup, frame optionally in LDS): frames whose index does
+//                     not fit LDS, and the pass behind fused_kernel that redoes an instance one of whose queries overflowed.
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
