@@ -368,6 +368,12 @@ int orbm_search_window_batch(orbm_ctx *ctx, int mode, int n_inst, const int32_t 
  * side effects of Fuse (Replace / AddObservation, :1259-1283) are replayed on the host in query order. */
 int orbm_search_window_free_batch(orbm_ctx *ctx, int n_inst, const int32_t *frame, const int32_t *qset, int dist_th,
                                   int chi2_gate, int32_t stride_q, int32_t *best_idx, int io_on_device);
+/* The same for query sets that are used once (the two directions of one SearchBySim3 call :1586-1710, the projections of one
+ * Fuse call :1185-1257 / :1390-1421): queries[k] travels with the call (host arrays, at most stride_q queries each; one
+ * pinned copy in, one out, one synchronisation; nothing uploaded beforehand, nothing to free).  Results as
+ * orbm_search_window_free_batch on uploaded copies of the same sets. */
+int orbm_search_window_free_once(orbm_ctx *ctx, int n_inst, const int32_t *frame, const orbm_win_queries *queries, int dist_th,
+                                 int chi2_gate, int32_t stride_q, int32_t *best_idx);
 
 /* ---- a6 / a11 as ONE call per search: what a tracking thread issues per frame (Tracking.cc:1152, 1549-1560, 1865 -- one
  * fresh query set into one resident frame).  The query arrays travel with the call (one pinned host->device copy together

@@ -18,7 +18,7 @@ SYMBOLS = [
     "orbm_frames_upload", "orbm_frames_free", "orbm_frame_set_mp_flags", "orbm_frame_grid_download",
     "orbm_proj_queries_upload", "orbm_win_queries_upload", "orbm_queries_free",
     "orbm_hamming256_pairs", "orbm_distinctive_descriptors_batch", "orbm_stereo_match_batch", "orbm_bf2nn_batch", "orbm_search_bow_batch", "orbm_search_triang_batch",
-    "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_init",
+    "orbm_search_proj_points_batch", "orbm_search_window_batch", "orbm_search_window_free_batch", "orbm_search_window_free_once", "orbm_search_init",
     "orbm_vocab_upload", "orbm_vocab_free", "orbm_frames_compute_bow", "orbm_vocab_transform", "orbm_frame_fv_download",
     "orbm_bowvecs_upload", "orbm_bowvecs_free", "orbm_bow_score_batch", "orbm_bowvec_download",
     "orbm_popcount_peak", "orbm_search_bow_batch_noalloc",
@@ -75,6 +75,7 @@ def load():
     L.orbm_search_proj_points_batch.argtypes = [vp, C.c_int, vp, vp, f32, f32, vp, i32, vp, vp, C.c_int]
     L.orbm_search_window_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, i32, vp, vp, C.c_int]
     L.orbm_search_window_free_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, i32, vp, C.c_int]
+    L.orbm_search_window_free_once.argtypes = [vp, C.c_int, vp, C.POINTER(CWinQueries), C.c_int, C.c_int, i32, vp]
     L.orbm_search_init.argtypes = [vp, i32, i32, vp, C.c_int, f32, C.c_int, vp]
     L.orbm_vocab_upload.argtypes = [vp, C.POINTER(CVocabView), C.POINTER(i32)]
     L.orbm_vocab_free.argtypes = [vp, i32]

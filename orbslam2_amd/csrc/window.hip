@@ -2556,3 +2556,71 @@ extern "C" int orbm_search_window_free_batch(orbm_ctx *ctx, int n_inst, const in
     HIPCHK(ctx, hipGetLastError());
     return io.finish();
 }
+
+// The same with query sets that are used once (SearchBySim3's two directions, Fuse of one keyframe: LoopClosing.cc / LocalMapping
+// call them with fresh projections every time): the arrays of all n_inst sets, their table and the id lists go to the device
+// as ONE pinned copy with the search, nothing is uploaded beforehand or freed afterwards (see search_once above).
+extern "C" int orbm_search_window_free_once(orbm_ctx *ctx, int n_inst, const int32_t *frame, const orbm_win_queries *queries,
+                                            int dist_th, int chi2_gate, int32_t stride_q, int32_t *best_idx) {
+    if (!ctx) return ORBM_EINVAL;
+    if (n_inst < 0 || (n_inst > 0 && (!frame || !queries || !best_idx)) || stride_q < 0)
+        return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_once: null argument or negative size");
+    if (n_inst == 0 || stride_q == 0) return ORBM_OK;
+    if (n_inst > 4096) return orbm_fail(ctx, ORBM_ELIMIT, "search_window_free_once: at most 4096 query sets per call");
+    int rc = orbm_check_frames(ctx, n_inst, frame, "frame");
+    if (rc) return rc;
+    size_t bytes = 0;
+    bool ragged = false;
+    for (int k = 0; k < n_inst; k++) {
+        const orbm_win_queries &q = queries[k];
+        if (q.n < 0 || q.n > stride_q) return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_once: set %d has %d queries, stride_q is %d", k, q.n, stride_q);
+        if (q.n > 0 && (!q.desc || !q.u || !q.v || !q.radius || !q.min_level || !q.max_level))
+            return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_once: null query array in set %d", k);
+        if (chi2_gate && q.n > 0 && !q.ur) return orbm_fail(ctx, ORBM_EINVAL, "search_window_free_once: chi2_gate needs the query set's ur array");
+        bytes += (size_t)q.n * 64 + 10 * 256;
+        ragged = ragged || q.n != stride_q;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t out_elems = (size_t)n_inst * stride_q;
+    rc = orbm_ws_reserve(ctx, bytes + (size_t)n_inst * (sizeof(QSetDev) + 8) + out_elems * 4 + 8192);
+    if (rc) return rc;
+    IoStage io(ctx, 0);
+    std::vector<QSetDev> tab((size_t)n_inst);
+    std::vector<int32_t> ids(2 * (size_t)n_inst);
+    std::vector<std::vector<uint8_t>> fl((size_t)n_inst);
+    static const uint8_t zero16[16] = {0};
+    for (int k = 0; k < n_inst; k++) {
+        const orbm_win_queries &q = queries[k];
+        const size_t n = (size_t)q.n;
+        QSetDev &qs = tab[k];
+        memset(&qs, 0, sizeof qs);
+        qs.n = q.n; qs.kind = 1;
+        const void *d;
+        auto put = [&](const void *p, size_t b, const void **out) { return io.in(n ? p : (const void *)zero16, std::max<size_t>(b, 16), out); };
+        if ((rc = put(q.desc, n * 32, &d))) return rc; qs.desc = (const uint32_t *)d;
+        if ((rc = put(q.u, n * 4, &d))) return rc; qs.f0 = (const float *)d;
+        if ((rc = put(q.v, n * 4, &d))) return rc; qs.f1 = (const float *)d;
+        if ((rc = put(q.radius, n * 4, &d))) return rc; qs.f2 = (const float *)d;
+        if (q.ur) { if ((rc = put(q.ur, n * 4, &d))) return rc; qs.f3 = (const float *)d; }
+        if ((rc = put(q.min_level, n * 4, &d))) return rc; qs.l0 = (const int32_t *)d;
+        if ((rc = put(q.max_level, n * 4, &d))) return rc; qs.l1 = (const int32_t *)d;
+        if (q.flags) { if ((rc = put(q.flags, n, &d))) return rc; }
+        else { fl[k].assign(std::max<size_t>(n, 16), ORBM_Q_VALID | ORBM_Q_OBS); if ((rc = io.in(fl[k].data(), fl[k].size(), &d))) return rc; }
+        qs.flags = (const uint8_t *)d;
+        ids[k] = frame[k]; ids[(size_t)n_inst + k] = k;
+    }
+    const void *dtab, *dids; void *dout;
+    if ((rc = io.in(tab.data(), tab.size() * sizeof(QSetDev), &dtab)) || (rc = io.in(ids.data(), ids.size() * 4, &dids)) ||
+        (rc = io.out(best_idx, out_elems * 4, &dout)))
+        return rc;
+    if (ragged) HIPCHK(ctx, hipMemsetAsync(dout, 0xFF, out_elems * 4, ctx->stream));   // rows beyond a set's n stay -1
+    WinParams P;
+    memset(&P, 0, sizeof P);
+    P.frames = ctx->d_frames; P.qsets = (const QSetDev *)dtab;
+    P.frame_ids = (const int32_t *)dids; P.qset_ids = (const int32_t *)dids + n_inst;
+    P.out = (int32_t *)dout; P.dist_th = dist_th; P.stride = stride_q;
+    const int chunks = (stride_q + 255) / 256;
+    hipLaunchKernelGGL(free_kernel, dim3((unsigned)(n_inst * chunks)), dim3(256), 0, ctx->stream, P, chunks, chi2_gate);
+    HIPCHK(ctx, hipGetLastError());
+    return io.finish();
+}

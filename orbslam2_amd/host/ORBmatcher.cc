@@ -324,11 +324,10 @@ void RunFree(const vector<const WinQ *> &qs, const vector<int32_t> &frame_ids, i
     vector<orbm_win_queries> views(K);
     int stride = 1;
     for (int k = 0; k < K; k++) { views[k] = qs[k]->View(true, false); stride = max(stride, views[k].n); }
-    vector<int32_t> qid(K, -1), flat((size_t)K * stride, -1);
-    Check(orbm_win_queries_upload(Ctx(), K, views.data(), qid.data()), "orbm_win_queries_upload");
-    int rc = orbm_search_window_free_batch(Ctx(), K, frame_ids.data(), qid.data(), dist_th, chi2 ? 1 : 0, stride, flat.data(), 0);
-    orbm_queries_free(Ctx(), K, qid.data());
-    Check(rc, "orbm_search_window_free_batch");
+    vector<int32_t> flat((size_t)K * stride, -1);
+    // one call: the query sets travel with the search (one pinned copy in, one out, one synchronisation)
+    Check(orbm_search_window_free_once(Ctx(), K, frame_ids.data(), views.data(), dist_th, chi2 ? 1 : 0, stride, flat.data()),
+          "orbm_search_window_free_once");
     best.resize(K);
     for (int k = 0; k < K; k++) best[k].assign(flat.begin() + (size_t)k * stride, flat.begin() + (size_t)k * stride + views[k].n);
 }

@@ -395,6 +395,16 @@ class Context:
                                                         stride_q, _addr(best), 0))
         return best[:k]
 
+    def search_window_free_once(self, frames, query_sets, dist_th: int, chi2_gate: bool, stride_q: int):
+        """orbm_search_window_free_once: the query sets travel with the call -> best[k, stride_q]"""
+        from .views import CWinQueries
+        fr = np.ascontiguousarray(frames, np.int32)
+        k = len(fr)
+        views = (CWinQueries * max(k, 1))(*[q.view() for q in query_sets])
+        best = np.full((max(k, 1), max(stride_q, 1)), -1, np.int32)
+        self._chk(self._L.orbm_search_window_free_once(self._h, k, _addr(fr), views, dist_th, int(chi2_gate), stride_q, _addr(best)))
+        return best[:k]
+
     # ---- a5 ----
     def search_init(self, f1: int, f2: int, prev_xy: np.ndarray, window: int, ratio: float, check_ori: bool):
         prev = np.ascontiguousarray(prev_xy, np.float32).copy()

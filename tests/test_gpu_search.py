@@ -444,6 +444,12 @@ def test_window_free_parity(ctx, orc, chi2, dist_th, stereo):
         assert (best[k, q.n:] == -1).all()
         tot += (wb >= 0).sum()
     assert tot > 200
+    # the same sets travelling with the call (orbm_search_window_free_once), and one set alone (no ragged rows)
+    best1 = ctx.search_window_free_once(fids, [i[1] for i in insts], dist_th, chi2, stride_q=2500)
+    assert np.array_equal(best1, best)
+    for k, (f, q) in enumerate(insts):
+        b = ctx.search_window_free_once(fids[k:k + 1], [q], dist_th, chi2, stride_q=q.n)
+        assert np.array_equal(b[0], best[k, :q.n]), k
     ctx.free_frames(fids); ctx.free_queries(qids)
 
 
