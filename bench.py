@@ -129,6 +129,15 @@ def cpu_baseline(kfs, n_store):
     while time.perf_counter() - t1 < 1.0:
         orc.search_init(i1, i2, iprev, 100, 0.9, True); c1_n += 1
     c1_us = (time.perf_counter() - t1) * 1e6 / c1_n
+    # the two per-frame tracking searches of `extra.track_*`, one core
+    fw, qw = synth.window_instance(700, 0, n=N_FEAT, n_queries=1500, th=7.0, stereo=True)
+    fp5, qp5 = synth.proj_instance(seed=synth.SEED0 + 9, n=N_FEAT, n_queries=5000)
+    trk = {}
+    for key, fn in (("track_cur_last_1500q_ms", lambda: orc.search_window(0, fw, qw, 100, True)), ("track_local_map_5000q_ms", lambda: orc.search_proj_points(fp5, qp5, 3.0, 0.8))):
+        t1 = time.perf_counter(); nrep = 0
+        while time.perf_counter() - t1 < 0.3:
+            fn(); nrep += 1
+        trk[key] = round((time.perf_counter() - t1) * 1e3 / nrep, 4)
     # C4: SearchByBoW(KF,KF) over the pair list `extra.search_bow_kfkf_*` runs: one core (time + the reference's distance
     # evaluations per pair, the oracle's counter), then all cores, one pair per task
     ia, ib = pair_list(np.random.default_rng(3), np.arange(nk), 8192)
@@ -180,6 +189,7 @@ def cpu_baseline(kfs, n_store):
             "search_by_projection_th5_single_instance_ms": round(proj_th[5.0][0], 3), "search_by_projection_th5_cmps": proj_th[5.0][1],
             "c1_search_init_us_per_call": round(c1_us, 2), "c1_search_init_cmps_per_call": c1_cmps, "c1_search_init_matches": c1_cnt,
             "c1_search_init_Gcmps": round(c1_cmps / c1_us / 1e3, 4),
+            **trk,
             "c1_note": "BASELINE config 1: SearchForInitialization, 2 frames x 1000 keypoints, 640x480, window 100, ratio 0.9, checkOri, one core",
             "search_bow_kfkf_ms_per_pair": round(bow_pair_ms, 4), "search_bow_kfkf_cmps_per_pair": round(bow_cmps / 256, 1),
             "search_bow_kfkf_all_cores_pairs_per_s": round(bow_pairs_s, 1),
@@ -344,6 +354,23 @@ def secondary(ctx, torch, dev, ids):
     out["c1_search_init_ms"] = round(best * 1e3, 4)
     out["c1_search_init_matches"] = int(c1)
     ctx.free_frames(iid)
+    # the two searches a tracking thread issues per frame, as single calls with host lists and outputs (resident frame and query
+    # set: the numpy -> ctypes marshalling of a fresh set is this wrapper's, not the library's; the C++ class sends the set with
+    # the call): SearchByProjection(Cur, Last) 1500 points th 7, SearchByProjection(F, 5000 map points) th 3
+    fw, qw = synth.window_instance(700, 0, n=N_FEAT, n_queries=1500, th=7.0, stereo=True)
+    fp, qp = synth.proj_instance(seed=synth.SEED0 + 9, n=N_FEAT, n_queries=5000)
+    tid2 = ctx.upload_frames([fw, fp]); wq = ctx.upload_win_queries([qw]); pq = ctx.upload_proj_queries([qp])
+    for key, fn in (("track_cur_last_1500q_ms", lambda: ctx.search_window(0, tid2[:1], wq, 100, True, N_FEAT)),
+                    ("track_local_map_5000q_ms", lambda: ctx.search_proj_points(tid2[1:], pq, 3.0, 0.8, N_FEAT))):
+        best = 1e30
+        for rep in range(8):
+            ctx.synchronize(); t0 = time.perf_counter()
+            fn()
+            dt1 = time.perf_counter() - t0
+            if rep:
+                best = min(best, dt1)
+        out[key] = round(best * 1e3, 4)
+    ctx.free_frames(tid2); ctx.free_queries(wq); ctx.free_queries(pq)
     # ComputeBoW on the device: descent of a k = 10, depth-6 tree (ORBvoc.txt's shape, 1.1 M nodes, synthetic) with every
     # descriptor of 96 keyframes + FeatureVector build, in one call; then one frame alone.  (Runs last: it replaces the
     # FeatureVectors of these keyframes with those of the synthetic tree.)
