@@ -506,13 +506,30 @@ __device__ __forceinline__ v8i bf_expand_fp4(uint32_t w, uint32_t ones) {
                  (int)bf_and_or(w, sign, ones), 0, 0, 0, 0};
 }
 
-// PIPE: 0 plain, 1 with s_setprio around the products (+3..4 % sustained: the matrix pipe idles less), 10-12 timing diagnostics
+// Operands without a sign (PIPE 2).  The chip holds 2.0-2.1 GHz on +-1 operands and 2.25-2.3 GHz on non-negative ones
+// (scripts/ubench_mfma4c.hip: zeros 0.98 of the nominal peak, +-1 x +-1 0.82, {0,1} x +-1 0.81, {0,1} x {0,1} 0.93 -- the
+// sign is what costs the power, not the density).  A query bit becomes 0 / 2.0 (FP4 0x4), a candidate bit the COMPLEMENT as
+// 0 / 1.0 (FP4 0x2): the product sums to 2 * #(q = 1, c = 0) = 2 * (popcount(q) - popcount(q & c)), and with the candidate
+// row's popcount as the accumulator's initial value a result is  popcount(c) + 2 popcount(q) - 2 popcount(q & c)
+// = d + popcount(q):  the distance plus a per-lane constant, every value an integer in [0, 768], exact in f32.
+// Dword k of an operand takes bits k, k + 4, ... of the raw dword, at nibble bit `b` (1: value 1.0, 2: value 2.0).
+template <int B>
+__device__ __forceinline__ v8i bf_expand_nn(uint32_t w) {
+    constexpr uint32_t mask = B == 2 ? 0x44444444u : 0x22222222u;
+    return (v8i){(int)((w << B) & mask), (int)((w << (B - 1)) & mask), (int)((B == 2 ? w : w >> 1) & mask),
+                 (int)((w >> (3 - B)) & mask), 0, 0, 0, 0};
+}
+__device__ __forceinline__ int popc128(v4u x) { return __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w); }
+
+// PIPE: 2 the sign-free form (above; the default for large batches), 0 plain, 1 with s_setprio around the products (+3..4 % sustained: the matrix pipe idles less), 10-12 timing diagnostics
 template <bool WANT_DIST, int NT, int PIPE = 0>
-__global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__restrict__ table,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bf2nn_mfma4r_kernel(const FrameDev *__restrict__ table,
                                                            const int32_t *__restrict__ fa, const int32_t *__restrict__ fb,
                                                            int blocks_per_pair, float ratio, int th, int track_below, int stride,
                                                            int32_t *__restrict__ match, int32_t *__restrict__ best_d,
                                                            int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
+    constexpr bool NN = PIPE == 2;
+    extern __shared__ float s_pc[];    // NN: popcount of every candidate row (1024 for the padding rows), the accumulators' initial values
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int p = bid / blocks_per_pair;
     const int qb = bid - p * blocks_per_pair;
@@ -525,7 +542,13 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
     }
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
     const int qbase = qb * (4 * QW) + wave * QW;
-    if (qbase >= nA) {                 // a wave without queries (no barrier in this kernel: it simply leaves)
+    if (NN) {                          // the one barrier of this form: every wave of the workgroup, with or without queries
+        const gptr<const v4u> rows = (gptr<const v4u>)B.desc;
+        for (int r = tid; r < ((nB + 31) & ~31); r += 256)
+            s_pc[r] = r < nB ? (float)(popc128(rows[2 * (size_t)r]) + popc128(rows[2 * (size_t)r + 1])) : 1024.f;
+        __syncthreads();
+    }
+    if (qbase >= nA) {                 // a wave without queries simply leaves (no barrier below this line)
         for (int i = l; i < QW; i += 64) if (qbase + i < stride) match[(size_t)p * stride + qbase + i] = -1;
         return;
     }
@@ -533,19 +556,23 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
     uint32_t ones = 0x22222222u;
     asm volatile("" : "+v"(ones));
     v8i bq[NT][4];
+    // NN: the popcount of the lane's query of tile t, kept in LDS (read where a bound changes and at the end only; four more
+    // registers would cost the third wave per SIMD).  best / second hold (d + pq) << 16 | candidate in this form.
+    int *const s_pq = (int *)(s_pc + ((nB + 31) & ~31)) + tid;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int row = min(qbase + t * 32 + col, max(nA - 1, 0));
         const v4u x = ((gptr<const v4u>)A.desc)[2 * (size_t)row + h];
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int s = 0; s < 4; s++) bq[t][s] = bf_expand_fp4(w[s], ones);
+        for (int s = 0; s < 4; s++) bq[t][s] = NN ? bf_expand_nn<2>(w[s]) : bf_expand_fp4(w[s], ones);
+        if (NN) { const int half = popc128(x); s_pq[256 * t] = half + __shfl_xor(half, 32); }
     }
     uint32_t best[NT], second[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        best[t] = (256u << 16) | 0xFFFFu;
-        second[t] = (256u << 16) | 0xFFFFu;
+        best[t] = ((256u + (NN ? (uint32_t)s_pq[256 * t] : 0u)) << 16) | 0xFFFFu;
+        second[t] = best[t];
     }
     const int one = 0x7F7F7F7F;
     const gptr<const v4u> rowsB = (gptr<const v4u>)B.desc;
@@ -559,11 +586,15 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         bool neg = false;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
+            if (NN) {                  // a result is d + pq >= 0: relevant below bound + pq, nothing is ever negative
+                Ti[t] = __float_as_int((float)min(second[t] >> 16, (uint32_t)(track_below + s_pq[256 * t])));
+                continue;
+            }
             const float Tf = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
             Ti[t] = Tf >= 0.f ? __float_as_int(Tf) : (int)0x80000000;
             neg = neg || Tf < 0.f;
         }
-        anyneg = __any(neg);
+        anyneg = !NN && __any(neg);
     };
     set_bounds();
     // NL = the wave's tiles that hold queries (wave-uniform; the last wave of a 2000-row frame has three of four): tiles
@@ -572,22 +603,37 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
     constexpr int NL = decltype(nl_tag)::value;
     v4u nxt = nB8 > 0 ? fetch(0) : v4u{0, 0, 0, 0};
     v4u nxt2 = nB8 > 32 ? fetch(32) : nxt;          // candidate rows are requested two blocks ahead
+    // NN: register r of a result is candidate rb + 4 h + (r & 3) + 8 (r >> 2): four 16-byte LDS reads, the same address in
+    // every lane of a half
+    auto load_cinit = [&](int rb) -> v16f {
+        const v4f *cp = (const v4f *)(s_pc + rb + 4 * h);
+        v16f c;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const v4f x = cp[2 * j];
+            c[4 * j] = x.x; c[4 * j + 1] = x.y; c[4 * j + 2] = x.z; c[4 * j + 3] = x.w;
+        }
+        return c;
+    };
+    v16f cnext = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (NN && nB8 > 0) cnext = load_cinit(0);
     for (int rb = 0; rb < nB8; rb += 32) {
-        if (PIPE == 1 || PIPE == 3) __builtin_amdgcn_s_setprio(1);       // a wave that has matrix instructions to issue goes before waves that are ranking
+        if (PIPE == 1 || PIPE == 2 || PIPE == 3) __builtin_amdgcn_s_setprio(1);       // a wave that has matrix instructions to issue goes before waves that are ranking
         const v4u cur = nxt;
         nxt = nxt2;
         if (rb + 64 < nB8) nxt2 = fetch(rb + 64);
         const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
         v16f acc[NT];
-#pragma unroll
-        for (int t = 0; t < NL; t++) acc[t] = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        v16f cinit = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (NN) cinit = cnext;         // in the last tile's registers: its first product overwrites them in place
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0} : bf_expand_fp4(w[s], ones);   // 10-12: timing diagnostics (results are wrong)
+            const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0}                // 10-12: timing diagnostics (results are wrong)
+                        : NN ? bf_expand_nn<1>(~w[s]) : bf_expand_fp4(w[s], ones);
 #pragma unroll
             for (int t = 0; t < NL; t++)
-                acc[t] = PIPE == 3 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, one, 0, one)   // A/B: the scaled encoding
-                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], acc[t], 4, 4, 0, 0, 0, 0);
+                acc[t] = PIPE == 3 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], s == 0 ? cinit : acc[t], 4, 4, 0, one, 0, one)   // A/B: the scaled encoding
+                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], s == 0 ? cinit : acc[t], 4, 4, 0, 0, 0, 0);
         }
         if (PIPE == 10 || PIPE == 12) {
 #pragma unroll
@@ -598,30 +644,47 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
             }
             continue;
         }
-        if (PIPE == 1 || PIPE == 3) __builtin_amdgcn_s_setprio(0);
+        if (PIPE == 1 || PIPE == 2 || PIPE == 3) __builtin_amdgcn_s_setprio(0);
         // dot products are ranked as integers (a positive float orders like its bits, every negative float is a negative
-        // integer): eight v_max3_i32 per tile fold its sixteen values and the bound
-        bool fire = false;
+        // integer): eight v_max3_i32 (v_min3_i32 in the sign-free form) per tile fold its sixteen values and the bound
+        auto fold = [&](auto t0c, auto t1c) -> bool {
+            bool fire = false;
 #pragma unroll
-        for (int t = 0; t < NL; t++) {
-            int m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
+            for (int t = decltype(t0c)::value; t < decltype(t1c)::value; t++) {
+                int m;
+                if (NN) {                  // smallest of sixteen non-negative values and the bound
+                    m = min(min(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) m = max(max(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
-            fire = fire || m != Ti[t];
-        }
-        if (anyneg || __any(fire)) {
+                    for (int r = 2; r < 16; r += 2) m = min(min(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
+                } else {
+                    m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) m = max(max(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
+                }
+                fire = fire || m != Ti[t];
+            }
+            return fire;
+        };
+        auto exact = [&](auto t0c, auto t1c) {
             const int cand0 = rb + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int cand = cand0 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                for (int t = 0; t < NL; t++) {
-                    const uint32_t key = cand < nB ? ((uint32_t)((256 - (int)acc[t][r]) >> 1) << 16) | (uint32_t)cand : 0xFFFFFFFFu;
+                for (int t = decltype(t0c)::value; t < decltype(t1c)::value; t++) {
+                    const int d = NN ? (int)acc[t][r] : (256 - (int)acc[t][r]) >> 1;
+                    const uint32_t key = cand < nB ? ((uint32_t)d << 16) | (uint32_t)cand : 0xFFFFFFFFu;
                     second[t] = umed3(best[t], second[t], key); best[t] = min(best[t], key);
                 }
             }
             set_bounds();
-        }
+        };
+        constexpr std::integral_constant<int, 0> c0{};
+        constexpr std::integral_constant<int, NL> cn{};
+        if (anyneg || __any(fold(c0, cn))) exact(c0, cn);
+        // the next block's initial values, requested as soon as this block's results are dead: the reads complete under the
+        // loop's address arithmetic and the first expansion instead of in front of the first product
+        if (NN) cnext = load_cinit(min(rb + 32, nB8 - 32));
     }
     };
     const int nl = min(NT, (nA - qbase + 31) >> 5);
@@ -641,7 +704,8 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4r_kernel(const FrameDev *__res
         const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
         const int qi = qbase + t * 32 + col;
         if (h == 0 && qi < nA) {
-            const int bd = (int)(b >> 16), sd = (int)(s2 >> 16);
+            const int off = NN ? s_pq[256 * t] : 0;
+            const int bd = (int)(b >> 16) - off, sd = (int)(s2 >> 16) - off;
             const int bidx = bd >= 256 ? -1 : (int)(b & 0xFFFFu);
             int mm = -1;
             if (bd <= th && (float)bd < __fmul_rn(ratio, (float)sd)) { mm = bidx; accepted++; }  // :304-308
@@ -766,11 +830,11 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         HIPCHK(ctx, hipGetLastError());
         return io.finish();
     }
-    if (variant >= 12 && variant <= 20) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
+    if (variant >= 12 && variant <= 22) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
         // 15: by batch size (scripts/bf_small_perf.py).  Four tiles per wave amortise the expansion of a candidate fragment over
         // 16 MFMAs (3 waves per SIMD) and win from about a thousand 2000 x 2000 pairs; below that more, smaller
         // workgroups fill the chip sooner: two tiles from 32 pairs, one tile for a handful (one pair alone: 24 us).
-        int nt = variant == 12 ? 2 : variant == 13 || variant >= 16 ? 4 : 1;
+        int nt = variant == 12 ? 2 : variant == 13 || variant >= 16 ? 4 : 1;      // 16-17: A/B forms of four tiles
         if (variant == 15) {
             const long long wg4 = (long long)n_pairs * ((max_na + 511) / 512), wg2 = (long long)n_pairs * ((max_na + 255) / 256);
             nt = wg4 >= 3000 ? 4 : wg2 >= 256 ? 2 : 1;
@@ -779,11 +843,21 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         const int bpp = (max_na + per_block - 1) / per_block;
         const long long gridr = (long long)n_pairs * bpp;
         if (gridr > 0x7FFFFFFFLL) return orbm_fail(ctx, ORBM_ELIMIT, "bf2nn_batch: grid too large");
+        // sign-free operands (PIPE 2) for the large batches: the candidate frame's row popcounts sit in LDS, 4 bytes per row.
+        // The pair lists may live on the device, so the bound is the largest live frame of the context.
+        size_t nn_lds = 0;
+        if (nt == 4 && (variant == 15 || variant == 22)) {
+            int max_nb = 0;
+            if (!io_on_device) for (int p = 0; p < n_pairs; p++) max_nb = std::max(max_nb, ctx->h_frames[frame_b[p]].n);
+            else for (size_t i = 0; i < ctx->h_frames.size(); i++) if (ctx->frame_arena[i] >= 0) max_nb = std::max(max_nb, ctx->h_frames[i].n);
+            if (max_nb <= 8192) nn_lds = (size_t)((max_nb + 31) & ~31) * 4 + 256 * 4 * 4;      // + the queries' popcounts
+        }
 #define MF4R_LAUNCH(WD, NTT, ...)                                                                                                \
-        hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT, ##__VA_ARGS__>), dim3((unsigned)gridr), dim3(256), 0, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
+        hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT, ##__VA_ARGS__>), dim3((unsigned)gridr), dim3(256), lds, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
                            (const int32_t *)dfb, bpp, ratio, th, track_below, stride, (int32_t *)dm, (int32_t *)dbd, (int32_t *)dsd, (int32_t *)dc)
         hipEvent_t *tev = orbm_timing_slot(ctx);           // orbm_kernel_timing: this launch alone, on its stream
         if (tev) HIPCHK(ctx, hipEventRecord(tev[0], ctx->stream));
+        size_t lds = 0;
         if (variant == 13) { if (best_d || second_d) MF4R_LAUNCH(true, 4); else MF4R_LAUNCH(false, 4); }     // A/B: without s_setprio
         else if (variant == 16) { if (best_d || second_d) MF4R_LAUNCH(true, 4, 3); else MF4R_LAUNCH(false, 4, 3); }
 #ifdef ORBM_DIAG
@@ -793,7 +867,8 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
 #endif
         else if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
         else if (nt == 1) { if (best_d || second_d) MF4R_LAUNCH(true, 1); else MF4R_LAUNCH(false, 1); }
-        else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }
+        else if (nn_lds) { lds = nn_lds; if (best_d || second_d) MF4R_LAUNCH(true, 4, 2); else MF4R_LAUNCH(false, 4, 2); }
+        else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }     // 17 (and frames above 8192 rows): the +-1 form with four tiles; 22: the sign-free form whatever the batch size
 #undef MF4R_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         if (tev) HIPCHK(ctx, hipEventRecord(tev[1], ctx->stream));

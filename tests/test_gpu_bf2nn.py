@@ -95,13 +95,15 @@ def test_bf2nn_batch_many_pairs(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 22])
 def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     """The vector-ALU kernel (11) and its tile-shape variants, the track-everything variant, the opt-in early-abandon
     variant (8: the last 64 bits of a comparison are skipped once the first 192 already reach the tracking bound), the
     int8 MFMA form (9), the FP4 MFMA form fed from pre-expanded images through LDS (10) and the FP4 MFMA form fed from the
     raw rows with two / four / one query tiles per wave (12 / 13 / 14; the default picks among these by batch size, which
-    every other test of this file runs) all return the reference's matches, with and without the raw distances, across
+    every other test of this file runs), the four-tile form with +-1 operands (17) and with sign-free operands (22: candidate
+    bits complemented as 0 / 1, query bits as 0 / 2, row popcounts as the accumulators' initial values; what large batches
+    run) all return the reference's matches, with and without the raw distances, across
     thresholds and ratios."""
     from orbslam2_amd import _lib
     L = _lib.load()
@@ -124,7 +126,7 @@ def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 12, 13, 14])
+@pytest.mark.parametrize("variant", [0, 12, 13, 14, 22])
 def test_bf2nn_tile_boundaries_mixed_sizes(ctx, orc, variant):
     """Frames of every size around the 32-row tile and the 128 / 256 / 512-row workgroup boundaries, mixed in ONE launch
     (a wave's number of live query tiles, the last candidate block and the rows between a frame's n and the stride all
@@ -240,8 +242,10 @@ def test_bf2nn_bench_size_properties(ctx, orc):
     ctx.free_frames(ids)
 
 
-def test_bf2nn_every_distance_value_is_exact(ctx, orc):
-    """Every Hamming distance 0..256 through the matrix-core form (distance = (256 - dot) / 2 of +-1 images): for each d a
+@pytest.mark.parametrize("variant", [0, 17, 22])
+def test_bf2nn_every_distance_value_is_exact(ctx, orc, variant):
+    """Every Hamming distance 0..256 through the matrix-core forms (distance = (256 - dot) / 2 of +-1 images; 22: the
+    sign-free operands, result = distance + popcount(query) on top of the candidate row's popcount): for each d a
     pair whose candidates sit at exactly d, min(d + 3, 256) and 256 bits from the query (bit positions chosen at random,
     so every k step of the product takes part); best / second come back as exactly those values, and the accept decision
     flips where the reference's does (th = d, th = d - 1; the ratio boundary)."""
@@ -261,16 +265,59 @@ def test_bf2nn_every_distance_value_is_exact(ctx, orc):
         want.append((d, d2))
     ids = ctx.upload_frames(frames)
     fa, fb = ids[0::2], ids[1::2]
-    for ratio, th in ((0.75, 50), (1.0, 256), (0.99, 100), (2.0, 0)):
-        counts, match, bd, sd = ctx.bf2nn(fa, fb, ratio, th, stride=1)
-        c2, m2, _, _ = ctx.bf2nn(fa, fb, ratio, th, stride=1, want_dist=False)
-        assert np.array_equal(counts, c2) and np.array_equal(match, m2)
-        for d, (wb, ws) in enumerate(want):
-            assert (bd[d, 0], sd[d, 0]) == (wb, ws), (d, bd[d, 0], sd[d, 0])
-            accept = wb <= th and np.float32(wb) < np.float32(ratio) * np.float32(ws)
-            assert match[d, 0] == (2 if accept else -1) and counts[d] == int(accept), (ratio, th, d)
-            wc, wm, wbd, wsd, _ = orc.bf2nn(frames[2 * d], frames[2 * d + 1], ratio, th)
-            assert wc == counts[d] and wm[0] == match[d, 0] and wbd[0] == wb and wsd[0] == ws
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    try:
+        L.orbm__bf2nn_variant(variant)
+        for ratio, th in ((0.75, 50), (1.0, 256), (0.99, 100), (2.0, 0)):
+            counts, match, bd, sd = ctx.bf2nn(fa, fb, ratio, th, stride=1)
+            c2, m2, _, _ = ctx.bf2nn(fa, fb, ratio, th, stride=1, want_dist=False)
+            assert np.array_equal(counts, c2) and np.array_equal(match, m2)
+            for d, (wb, ws) in enumerate(want):
+                assert (bd[d, 0], sd[d, 0]) == (wb, ws), (d, bd[d, 0], sd[d, 0])
+                accept = wb <= th and np.float32(wb) < np.float32(ratio) * np.float32(ws)
+                assert match[d, 0] == (2 if accept else -1) and counts[d] == int(accept), (ratio, th, d)
+                wc, wm, wbd, wsd, _ = orc.bf2nn(frames[2 * d], frames[2 * d + 1], ratio, th)
+                assert wc == counts[d] and wm[0] == match[d, 0] and wbd[0] == wb and wsd[0] == ws
+    finally:
+        L.orbm__bf2nn_variant(0)
+    ctx.free_frames(ids)
+
+
+@pytest.mark.parametrize("variant", [0, 17, 22])
+def test_bf2nn_extreme_popcounts(ctx, orc, variant):
+    """Descriptors of every weight: all zeros, all ones, single bits, one zero bit, sparse and dense rows on both sides (in
+    the sign-free form a result is distance + popcount(query) on top of popcount(candidate): 0 .. 768), 70 x 70 rows so
+    that candidate blocks mix the extremes, with raw distances and without, thresholds up to 256."""
+    rng = np.random.default_rng(31)
+    rows = [np.zeros(32, np.uint8), np.full(32, 255, np.uint8)]
+    for k in (0, 7, 100, 255):
+        one = np.zeros(256, np.uint8); one[k] = 1
+        rows.append(np.packbits(one)); rows.append(np.packbits(1 - one))
+    for p in (0.02, 0.1, 0.3, 0.5, 0.7, 0.9, 0.98):
+        for _ in range(8):
+            rows.append(np.packbits((rng.random(256) < p).astype(np.uint8)))
+    rows = np.stack(rows)
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    fa = synth.make_frame(rng, rows, rng.permutation(len(rows)), with_fv=False, p_flip=0.0)
+    fb = synth.make_frame(rng, rows, rng.permutation(len(rows)), with_fv=False, p_flip=0.0)
+    fc = synth.make_frame(rng, rows, rng.permutation(len(rows)), with_fv=False, p_flip=0.01)
+    ids = ctx.upload_frames([fa, fb, fc])
+    fr = [fa, fb, fc]
+    try:
+        L.orbm__bf2nn_variant(variant)
+        for ratio, th in ((0.75, 50), (1.0, 256), (1.5, 200), (0.9, 128)):
+            for want_dist in (True, False):
+                pa, pb = [0, 1, 2, 0, 2], [1, 0, 0, 2, 2]
+                counts, match, bd, sd = ctx.bf2nn(ids[pa], ids[pb], ratio, th, stride=len(rows), want_dist=want_dist)
+                for k, (i, j) in enumerate(zip(pa, pb)):
+                    wc, wm, wbd, wsd, _ = orc.bf2nn(fr[i], fr[j], ratio, th)
+                    assert counts[k] == wc and np.array_equal(match[k], wm), (variant, ratio, th, want_dist, i, j)
+                    if want_dist:
+                        assert np.array_equal(bd[k], wbd) and np.array_equal(sd[k], wsd), (variant, ratio, th, i, j)
+    finally:
+        L.orbm__bf2nn_variant(0)
     ctx.free_frames(ids)
 
 
