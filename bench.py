@@ -645,7 +645,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp4 e2m1 (+-1 per descriptor bit, exact) x fp4 e2m1 -> f32 accumulate (exact integers)", "data": "synthetic",
+            "dtype": "fp4 e2m1 (candidate bits complemented as 0 / 1, query bits as 0 / 2: exact) x fp4 e2m1 -> f32 accumulate (exact integers)", "data": "synthetic",
             "config": {"workload": "brute-force 2-NN Hamming + TH_LOW + ratio test, 2000x2000 256-bit descriptors per keyframe pair "
                                    "(BASELINE configs[1]), batched over the pair triangle of the config-5 store (BASELINE configs[4])",
                        "store_keyframes": n_kf, "features_per_keyframe": N_FEAT, "pairs_in_triangle": n_kf * (n_kf - 1) // 2,
@@ -668,9 +668,11 @@ def main():
             "setup_s": round(setup_s, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_MFMA_TFLOPS, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "bf2nn_mfma4r_kernel<false,4,1>", "kernel_ms": round(kms, 4), "call_ms": round(call_ms, 4),
+                         "kernel": "bf2nn_mfma4r_kernel<false,4,2>", "kernel_ms": round(kms, 4), "call_ms": round(call_ms, 4),
                          "flop_per_cmp": FLOP_PER_CMP, "achieved_T_cmps_per_s": round(achieved_tcmps, 4),
-                         "note": "Hamming distance = (256 - dot) / 2 of the +-1 images; algorithmic FLOP per launch = pairs x 2000 x 2000 "
+                         "note": "Hamming distance + popcount(query) = popcount(candidate) + dot of the sign-free images (candidate bits "
+                                 "complemented as 0 / 1, query bits as 0 / 2; the +-1 images of rounds 1-3, distance = (256 - dot) / 2, cost "
+                                 "the chip 10 % of its clock: extra.bf2nn_operand_ab); algorithmic FLOP per launch = pairs x 2000 x 2000 "
                                  "x 512; peak = 256 CUs x 4 SIMDs x 4096 FLOP/cycle (v_mfma_f32_32x32x64_f8f6f4, FP4) x 2.4 GHz. "
                                  "kernel_ms = HIP events the library records around the matching kernel on its stream (orbm_kernel_timing), "
                                  "averaged over every launch of the timed region; call_ms = events around the whole "
@@ -702,6 +704,27 @@ def main():
                         ex_out[f"c5_all_pairs_{name}_pairs_per_s"] = round(n_mine / s_dt, 1)
                         ex_out[f"c5_all_pairs_{name}_accepted_pairs"] = s_acc
                         ex_out[f"c5_all_pairs_{name}_record_bytes_per_pair"] = round((8 * n_mine + 4 * s_ent) / n_mine, 2)
+                    # the same launches with +-1 operands (what rounds 1-3 multiplied) and with the sign-free operands, sustained
+                    # and interleaved: same matches, different clock under the power limit
+                    from orbslam2_amd import _lib as _lib_ab
+                    ab = {17: [], 0: []}
+                    try:
+                        for rep in range(2):
+                            for v in (17, 0):
+                                _lib_ab.load().orbm__bf2nn_variant(v)
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0.record()
+                                for j in range(40):
+                                    s0 = (j % n_full) * P
+                                    ctx.allpairs_batch_dev(0, P, fa_all.data_ptr() + 4 * s0, fb_all.data_ptr() + 4 * s0, pid_all.data_ptr() + 4 * s0, RATIO,
+                                                           TH, True, N_FEAT, ACCEPT, summ[0].data_ptr(), lists[0].data_ptr(), LIST_CAP, summ[0].data_ptr() + 8 * P)
+                                e1.record(); torch.cuda.synchronize()
+                                ab[v].append(e0.elapsed_time(e1) / 40)
+                    finally:
+                        _lib_ab.load().orbm__bf2nn_variant(0)
+                    ex_out["bf2nn_operand_ab"] = {"pm1_operands_Gcmps": round(cmps_per_launch / (min(ab[17]) * 1e-3) / 1e9, 1),
+                                                  "sign_free_operands_Gcmps": round(cmps_per_launch / (min(ab[0]) * 1e-3) / 1e9, 1),
+                                                  "note": "40 launches of 16384 pairs per form and repetition, two repetitions interleaved, whole calls"}
                 ex_out.update(secondary(ctx, torch, dev, small))
                 res["extra"] = ex_out
             except Exception as e:  # secondary numbers must never break the headline line

@@ -508,16 +508,22 @@ __device__ __forceinline__ v8i bf_expand_fp4(uint32_t w, uint32_t ones) {
 
 // Operands without a sign (PIPE 2).  The chip holds 2.0-2.1 GHz on +-1 operands and 2.25-2.3 GHz on non-negative ones
 // (scripts/ubench_mfma4c.hip: zeros 0.98 of the nominal peak, +-1 x +-1 0.82, {0,1} x +-1 0.81, {0,1} x {0,1} 0.93 -- the
-// sign is what costs the power, not the density).  A query bit becomes 0 / 2.0 (FP4 0x4), a candidate bit the COMPLEMENT as
-// 0 / 1.0 (FP4 0x2): the product sums to 2 * #(q = 1, c = 0) = 2 * (popcount(q) - popcount(q & c)), and with the candidate
+// sign is what costs the power, not the density).  A query bit becomes 0 / weight, a candidate bit the COMPLEMENT as
+// 0 / (2 / weight): the product sums to 2 * #(q = 1, c = 0) = 2 * (popcount(q) - popcount(q & c)), and with the candidate
 // row's popcount as the accumulator's initial value a result is  popcount(c) + 2 popcount(q) - 2 popcount(q & c)
 // = d + popcount(q):  the distance plus a per-lane constant, every value an integer in [0, 768], exact in f32.
-// Dword k of an operand takes bits k, k + 4, ... of the raw dword, at nibble bit `b` (1: value 1.0, 2: value 2.0).
-template <int B>
-__device__ __forceinline__ v8i bf_expand_nn(uint32_t w) {
-    constexpr uint32_t mask = B == 2 ? 0x44444444u : 0x22222222u;
-    return (v8i){(int)((w << B) & mask), (int)((w << (B - 1)) & mask), (int)((B == 2 ? w : w >> 1) & mask),
-                 (int)((w >> (3 - B)) & mask), 0, 0, 0, 0};
+// Dword k of an operand takes bits k, k + 4, ... of the raw dword, and WITHOUT a sign bit to fill a bit may stay where it is
+// inside its nibble: FP4 E2M1 reads nibble bit 0 as 0.5, bit 1 as 1.0, bit 2 as 2.0, so a candidate fragment is three ANDs
+// (of the complement) and one shift + AND for the bits at position 3 (-> position 2) -- 5 instructions per 32 bits between
+// two groups of products where the +-1 form has 7.  The query side (expanded once per kernel) carries the weights that make
+// every product 2: 4.0 (0x6), 2.0 (0x4), 1.0 (0x2), 1.0.
+__device__ __forceinline__ v8i bf_expand_nn_cand(uint32_t w) {
+    const uint32_t n = ~w;
+    return (v8i){(int)(n & 0x11111111u), (int)(n & 0x22222222u), (int)(n & 0x44444444u), (int)(~(w >> 1) & 0x44444444u), 0, 0, 0, 0};
+}
+__device__ __forceinline__ v8i bf_expand_nn_query(uint32_t w) {
+    const uint32_t b0 = w & 0x11111111u;
+    return (v8i){(int)((b0 << 1) | (b0 << 2)), (int)((w & 0x22222222u) << 1), (int)((w & 0x44444444u) >> 1), (int)((w >> 2) & 0x22222222u), 0, 0, 0, 0};
 }
 __device__ __forceinline__ int popc128(v4u x) { return __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w); }
 
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
         const v4u x = ((gptr<const v4u>)A.desc)[2 * (size_t)row + h];
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int s = 0; s < 4; s++) bq[t][s] = NN ? bf_expand_nn<2>(w[s]) : bf_expand_fp4(w[s], ones);
+        for (int s = 0; s < 4; s++) bq[t][s] = NN ? bf_expand_nn_query(w[s]) : bf_expand_fp4(w[s], ones);
         if (NN) { const int half = popc128(x); s_pq[256 * t] = half + __shfl_xor(half, 32); }
     }
     uint32_t best[NT], second[NT];
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0}                // 10-12: timing diagnostics (results are wrong)
-                        : NN ? bf_expand_nn<1>(~w[s]) : bf_expand_fp4(w[s], ones);
+                        : NN ? bf_expand_nn_cand(w[s]) : bf_expand_fp4(w[s], ones);
 #pragma unroll
             for (int t = 0; t < NL; t++)
                 acc[t] = PIPE == 3 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[t][s], s == 0 ? cinit : acc[t], 4, 4, 0, one, 0, one)   // A/B: the scaled encoding
