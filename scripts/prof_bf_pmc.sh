@@ -22,12 +22,12 @@ for v in (17, 22):
     m = {k: sum(x) / len(x) for k, x in acc.items()}
     print("form", v, {k: round(x) for k, x in m.items()})
     if m:
-        simd_cycles = m["GRBM_GUI_ACTIVE"] * 256 * 4
+        simd_cycles = m["GRBM_GUI_ACTIVE"] / 8 * 256 * 4      # the counter is summed over the 8 XCDs
         print("   matrix pipe busy %.3f of SIMD-cycles; VALU instr per MFMA %.2f" % (m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"]))
     kt = []
     for f in glob.glob(f"gpurun_out/prof_bf_pmc/v{v}/**/*kernel_trace.csv", recursive=True):
         kt += [r for r in csv.DictReader(open(f)) if "mfma4r" in r["Kernel_Name"]]
     if kt and m:
         ns = sum(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in kt) / len(kt)
-        print("   kernel %.3f ms under the counters, clock estimate %.2f GHz" % (ns / 1e6, m["GRBM_GUI_ACTIVE"] / ns))
+        print("   kernel %.3f ms under the counters, clock estimate %.2f GHz" % (ns / 1e6, m["GRBM_GUI_ACTIVE"] / 8 / ns))
 P

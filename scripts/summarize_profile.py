@@ -9,7 +9,7 @@ with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-HEAD = "bf2nn_mfma4r"     # the headline kernel (bench.py also runs the other forms once each, in `extra`)
+HEAD = "bf2nn_mfma4r_kernel<false, 4, 2>"     # the headline kernel (bench.py also runs the other forms once each, in `extra`)
 def counters(sub, kern=HEAD):
     f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
     agg = collections.defaultdict(list)
