@@ -39,8 +39,18 @@ def test_grid_build_matches_oracle(ctx, orc, n):
     ctx.free_frames(ids)
 
 
+@pytest.mark.parametrize("variant", [0, 22])       # 22: the large-batch form (sign-free operands) on one pair
 @pytest.mark.parametrize("na,nb", [(2000, 2000), (1, 1), (513, 77), (64, 1025), (700, 0), (0, 300)])
-def test_bf2nn_parity(ctx, orc, na, nb):
+def test_bf2nn_parity(ctx, orc, na, nb, variant):
+    from orbslam2_amd import _lib
+    _lib.load().orbm__bf2nn_variant(variant)
+    try:
+        _bf2nn_parity(ctx, orc, na, nb)
+    finally:
+        _lib.load().orbm__bf2nn_variant(0)
+
+
+def _bf2nn_parity(ctx, orc, na, nb):
     rng = np.random.default_rng(na * 7 + nb)
     n = max(na, nb, 1)
     a, b = synth.bf_pair(seed=na * 31 + nb, n=n)
