@@ -534,8 +534,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
                                                            int blocks_per_pair, float ratio, int th, int track_below, int stride,
                                                            int32_t *__restrict__ match, int32_t *__restrict__ best_d,
                                                            int32_t *__restrict__ second_d, int32_t *__restrict__ counts) {
-    constexpr bool NN = PIPE == 2;
-    extern __shared__ float s_pc[];    // NN: popcount of every candidate row (1024 for the padding rows), the accumulators' initial values
+    constexpr bool NN = PIPE == 2 || PIPE == 4;
+    // DEF (PIPE 4): the last 64 bits of a comparison are DEFERRED.  A block's results after three of the four products are
+    // partial distances over 192 bits (+ the query's popcount over the same bits): lower bounds of the full ones, since the
+    // fourth product only adds.  They are ranked against the bound as usual, and only when some lane finds a partial result
+    // below its bound does the wave issue the fourth group of products, add the rows' last-64-bit popcounts and rank again.
+    // For pairs that share nothing (distance 128 +- 8, 192-bit part 96 +- 7, bound 67) that happens in about one block of
+    // twenty: a quarter of the products and of the expansion is not executed, results are identical.
+    constexpr bool DEF = PIPE == 4;
+    extern __shared__ float s_pc[];    // NN: popcount of every candidate row (DEF: of its first 192 bits; 1024 for the padding rows), the accumulators' initial values
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int p = bid / blocks_per_pair;
     const int qb = bid - p * blocks_per_pair;
@@ -548,10 +555,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     }
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, col = l & 31, h = l >> 5;
     const int qbase = qb * (4 * QW) + wave * QW;
+    // LDS: s_pc[nB8] | s_pq[4][256] (query popcounts: full | last 64 bits << 16) | DEF: s_tf[4][256] (the full bound as float
+    // bits) | DEF: s_bq3[4][256] x 16 B | DEF: s_pl[nB8] bytes (popcount of a candidate row's last 64 bits = dword 3 of both halves)
+    int *const s_pq = (int *)(s_pc + ((nB + 31) & ~31)) + tid;
+    int *const s_tf = s_pq + 4 * 256;
+    v4u *const s_bq3 = (v4u *)(s_pq - tid + 8 * 256) + tid;            // DEF: the lane's query fragments of the fourth product, [4][256] x 16 B (only the rare path reads them: 16 registers less in the loop)
+    uint8_t *const s_pl = (uint8_t *)(s_pq - tid + 8 * 256 + 4 * 256 * 4);
     if (NN) {                          // the one barrier of this form: every wave of the workgroup, with or without queries
         const gptr<const v4u> rows = (gptr<const v4u>)B.desc;
-        for (int r = tid; r < ((nB + 31) & ~31); r += 256)
-            s_pc[r] = r < nB ? (float)(popc128(rows[2 * (size_t)r]) + popc128(rows[2 * (size_t)r + 1])) : 1024.f;
+        for (int r = tid; r < ((nB + 31) & ~31); r += 256) {
+            float v = 1024.f;
+            int last = 0;
+            if (r < nB) {
+                const v4u x0 = rows[2 * (size_t)r], x1 = rows[2 * (size_t)r + 1];
+                last = DEF ? __popc(x0.w) + __popc(x1.w) : 0;
+                v = (float)(popc128(x0) + popc128(x1) - last);
+            }
+            s_pc[r] = v;
+            if (DEF) s_pl[r] = (uint8_t)last;
+        }
         __syncthreads();
     }
     if (qbase >= nA) {                 // a wave without queries simply leaves (no barrier below this line)
@@ -561,23 +583,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     const long long diag_c0 = PIPE == 10 ? clock64() : 0, diag_w0 = PIPE == 10 ? wall_clock64() : 0;
     uint32_t ones = 0x22222222u;
     asm volatile("" : "+v"(ones));
-    v8i bq[NT][4];
+    v8i bq[NT][DEF ? 3 : 4];
     // NN: the popcount of the lane's query of tile t, kept in LDS (read where a bound changes and at the end only; four more
     // registers would cost the third wave per SIMD).  best / second hold (d + pq) << 16 | candidate in this form.
-    int *const s_pq = (int *)(s_pc + ((nB + 31) & ~31)) + tid;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int row = min(qbase + t * 32 + col, max(nA - 1, 0));
         const v4u x = ((gptr<const v4u>)A.desc)[2 * (size_t)row + h];
         const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int s = 0; s < 4; s++) bq[t][s] = NN ? bf_expand_nn_query(w[s]) : bf_expand_fp4(w[s], ones);
-        if (NN) { const int half = popc128(x); s_pq[256 * t] = half + __shfl_xor(half, 32); }
+        for (int s = 0; s < (DEF ? 3 : 4); s++) bq[t][s] = NN ? bf_expand_nn_query(w[s]) : bf_expand_fp4(w[s], ones);
+        if (DEF) { const v8i f = bf_expand_nn_query(w[3]); s_bq3[256 * t] = (v4u){(uint32_t)f[0], (uint32_t)f[1], (uint32_t)f[2], (uint32_t)f[3]}; }
+        if (NN) {
+            const int half = popc128(x) | (DEF ? __popc(x.w) << 16 : 0);         // both counts at once: neither reaches 2^16
+            s_pq[256 * t] = half + __shfl_xor(half, 32);
+        }
     }
     uint32_t best[NT], second[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        best[t] = ((256u + (NN ? (uint32_t)s_pq[256 * t] : 0u)) << 16) | 0xFFFFu;
+        best[t] = ((256u + (NN ? (uint32_t)s_pq[256 * t] & 0xFFFFu : 0u)) << 16) | 0xFFFFu;
         second[t] = best[t];
     }
     const int one = 0x7F7F7F7F;
@@ -593,7 +618,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             if (NN) {                  // a result is d + pq >= 0: relevant below bound + pq, nothing is ever negative
-                Ti[t] = __float_as_int((float)min(second[t] >> 16, (uint32_t)(track_below + s_pq[256 * t])));
+                const uint32_t pk = (uint32_t)s_pq[256 * t];
+                const uint32_t tfull = min(second[t] >> 16, (uint32_t)track_below + (pk & 0xFFFFu));
+                Ti[t] = __float_as_int((float)(tfull - (pk >> 16)));           // DEF: the bound of the 192-bit part (pk >> 16 is 0 otherwise)
+                if (DEF) s_tf[256 * t] = __float_as_int((float)tfull);
                 continue;
             }
             const float Tf = (float)(256 - 2 * (int)min(second[t] >> 16, (uint32_t)track_below));
@@ -624,7 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
     v16f cnext = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (NN && nB8 > 0) cnext = load_cinit(0);
     for (int rb = 0; rb < nB8; rb += 32) {
-        if (PIPE == 1 || PIPE == 2 || PIPE == 3) __builtin_amdgcn_s_setprio(1);       // a wave that has matrix instructions to issue goes before waves that are ranking
+        if (PIPE == 1 || NN || PIPE == 3) __builtin_amdgcn_s_setprio(1);       // a wave that has matrix instructions to issue goes before waves that are ranking
         const v4u cur = nxt;
         nxt = nxt2;
         if (rb + 64 < nB8) nxt2 = fetch(rb + 64);
@@ -633,7 +661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
         v16f cinit = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (NN) cinit = cnext;         // in the last tile's registers: its first product overwrites them in place
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < (DEF ? 3 : 4); s++) {
             const v8i a = PIPE == 11 || PIPE == 12 ? (v8i){(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0}                // 10-12: timing diagnostics (results are wrong)
                         : NN ? bf_expand_nn_cand(w[s]) : bf_expand_fp4(w[s], ones);
 #pragma unroll
@@ -650,27 +678,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
             }
             continue;
         }
-        if (PIPE == 1 || PIPE == 2 || PIPE == 3) __builtin_amdgcn_s_setprio(0);
+        if (PIPE == 1 || NN || PIPE == 3) __builtin_amdgcn_s_setprio(0);
         // dot products are ranked as integers (a positive float orders like its bits, every negative float is a negative
         // integer): eight v_max3_i32 (v_min3_i32 in the sign-free form) per tile fold its sixteen values and the bound
-        auto fold = [&](auto t0c, auto t1c) -> bool {
+        auto fold = [&](auto t0c, auto t1c, auto full) -> bool {
             bool fire = false;
 #pragma unroll
             for (int t = decltype(t0c)::value; t < decltype(t1c)::value; t++) {
                 int m;
+                const int Tb = decltype(full)::value ? s_tf[256 * t] : Ti[t];       // the full bound is read where it is used (rare path: no registers held for it)
                 if (NN) {                  // smallest of sixteen non-negative values and the bound
-                    m = min(min(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
+                    m = min(min(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Tb);
 #pragma unroll
                     for (int r = 2; r < 16; r += 2) m = min(min(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
                 } else {
-                    m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Ti[t]);
+                    m = max(max(__float_as_int(acc[t][0]), __float_as_int(acc[t][1])), Tb);
 #pragma unroll
                     for (int r = 2; r < 16; r += 2) m = max(max(m, __float_as_int(acc[t][r])), __float_as_int(acc[t][r + 1]));
                 }
-                fire = fire || m != Ti[t];
+                fire = fire || m != Tb;
             }
             return fire;
         };
+        constexpr std::false_type part{};
+        constexpr std::true_type whole{};
         auto exact = [&](auto t0c, auto t1c) {
             const int cand0 = rb + 4 * h;
 #pragma unroll
@@ -687,7 +718,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
         };
         constexpr std::integral_constant<int, 0> c0{};
         constexpr std::integral_constant<int, NL> cn{};
-        if (anyneg || __any(fold(c0, cn))) exact(c0, cn);
+        if (DEF) {
+            if (__any(fold(c0, cn, part))) {
+                // some 192-bit part is below its bound: the last 64 bits after all, for the whole block.  First the rows'
+                // last-64-bit popcounts onto the results at hand (integers: the order of the additions does not matter), then
+                // the fourth group of products on top
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t pl4 = *(const uint32_t *)(s_pl + rb + 4 * h + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float add = (float)((pl4 >> (8 * i)) & 255u);
+#pragma unroll
+                        for (int t = 0; t < NL; t++) acc[t][4 * j + i] += add;
+                    }
+                }
+                const v8i a = bf_expand_nn_cand(w[3]);
+#pragma unroll
+                for (int t = 0; t < NL; t++) {
+                    const v4u f = s_bq3[256 * t];
+                    const v8i b3 = {(int)f.x, (int)f.y, (int)f.z, (int)f.w, 0, 0, 0, 0};
+                    acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b3, acc[t], 4, 4, 0, 0, 0, 0);
+                }
+                if (__any(fold(c0, cn, whole))) exact(c0, cn);
+            }
+        } else if (anyneg || __any(fold(c0, cn, part))) exact(c0, cn);
         // the next block's initial values, requested as soon as this block's results are dead: the reads complete under the
         // loop's address arithmetic and the first expansion instead of in front of the first product
         if (NN) cnext = load_cinit(min(rb + 32, nB8 - 32));
@@ -710,7 +765,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void b
         const uint32_t b = min(best[t], pb), s2 = min(max(best[t], pb), min(second[t], ps));
         const int qi = qbase + t * 32 + col;
         if (h == 0 && qi < nA) {
-            const int off = NN ? s_pq[256 * t] : 0;
+            const int off = NN ? s_pq[256 * t] & 0xFFFF : 0;
             const int bd = (int)(b >> 16) - off, sd = (int)(s2 >> 16) - off;
             const int bidx = bd >= 256 ? -1 : (int)(b & 0xFFFFu);
             int mm = -1;
@@ -836,7 +891,7 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         HIPCHK(ctx, hipGetLastError());
         return io.finish();
     }
-    if (variant >= 12 && variant <= 22) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
+    if (variant >= 12 && variant <= 24) {     // FP4 MFMA from the raw rows, no LDS (12: two query tiles per wave, 13: four, 14: one)
         // 15: by batch size (scripts/bf_small_perf.py).  Four tiles per wave amortise the expansion of a candidate fragment over
         // 16 MFMAs (3 waves per SIMD) and win from about a thousand 2000 x 2000 pairs; below that more, smaller
         // workgroups fill the chip sooner: two tiles from 32 pairs, one tile for a handful (one pair alone: 24 us).
@@ -852,11 +907,11 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
         // sign-free operands (PIPE 2) for the large batches: the candidate frame's row popcounts sit in LDS, 4 bytes per row.
         // The pair lists may live on the device, so the bound is the largest live frame of the context.
         size_t nn_lds = 0;
-        if (nt == 4 && (variant == 15 || variant == 22)) {
+        if (nt == 4 && (variant == 15 || variant == 22 || variant == 24)) {      // 24: deferred form whatever the batch size (if the bound allows)
             int max_nb = 0;
             if (!io_on_device) for (int p = 0; p < n_pairs; p++) max_nb = std::max(max_nb, ctx->h_frames[frame_b[p]].n);
             else for (size_t i = 0; i < ctx->h_frames.size(); i++) if (ctx->frame_arena[i] >= 0) max_nb = std::max(max_nb, ctx->h_frames[i].n);
-            if (max_nb <= 8192) nn_lds = (size_t)((max_nb + 31) & ~31) * 4 + 256 * 4 * 4;      // + the queries' popcounts
+            if (max_nb <= 8192) nn_lds = (size_t)((max_nb + 31) & ~31) * 5 + 2 * 256 * 4 * 4 + 256 * 4 * 16;      // + the queries' popcounts and full bounds, their fourth fragments, the rows' last-64-bit counts
         }
 #define MF4R_LAUNCH(WD, NTT, ...)                                                                                                \
         hipLaunchKernelGGL((bf2nn_mfma4r_kernel<WD, NTT, ##__VA_ARGS__>), dim3((unsigned)gridr), dim3(256), lds, ctx->stream, ctx->d_frames, (const int32_t *)dfa, \
@@ -873,6 +928,9 @@ extern "C" int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame
 #endif
         else if (nt == 2) { if (best_d || second_d) MF4R_LAUNCH(true, 2); else MF4R_LAUNCH(false, 2); }
         else if (nt == 1) { if (best_d || second_d) MF4R_LAUNCH(true, 1); else MF4R_LAUNCH(false, 1); }
+        // the deferred form pays while a lower bound over 192 bits (96 +- 7 for unrelated descriptors) rarely reaches the
+        // tracking bound: matches only, and an acceptance rule whose bound stays below 72 (th 50 at ratio 0.75: 67)
+        else if (nn_lds && !best_d && !second_d && track_below <= 72 && variant != 22) { lds = nn_lds; MF4R_LAUNCH(false, 4, 4); }
         else if (nn_lds) { lds = nn_lds; if (best_d || second_d) MF4R_LAUNCH(true, 4, 2); else MF4R_LAUNCH(false, 4, 2); }
         else { if (best_d || second_d) MF4R_LAUNCH(true, 4, 1); else MF4R_LAUNCH(false, 4, 1); }     // 17 (and frames above 8192 rows): the +-1 form with four tiles; 22: the sign-free form whatever the batch size
 #undef MF4R_LAUNCH

@@ -15,6 +15,8 @@ ids = ctx.upload_frames(kfs)
 P = 16384
 rng = np.random.default_rng(0)
 pa = rng.integers(0, 96, P); pb = (pa + rng.integers(8, 88, P)) % 96      # at least 8 keyframes apart: no shared landmarks
+if os.environ.get("ORBM_BF_NEAR") == "1":      # neighbouring keyframes instead: most candidate blocks hold a true match of some query
+    pb = (pa + rng.integers(1, 3, P)) % 96
 dev = torch.device("cuda:0")
 fa = torch.tensor(ids[pa], dtype=torch.int32, device=dev); fb = torch.tensor(ids[pb], dtype=torch.int32, device=dev)
 match = torch.empty((P, 2000), dtype=torch.int32, device=dev); counts = torch.empty(P, dtype=torch.int32, device=dev)

@@ -39,7 +39,7 @@ def test_grid_build_matches_oracle(ctx, orc, n):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 22])       # 22: the large-batch form (sign-free operands) on one pair
+@pytest.mark.parametrize("variant", [0, 22, 24])       # 22 / 24: the large-batch forms (sign-free operands; last 64 bits deferred) on one pair
 @pytest.mark.parametrize("na,nb", [(2000, 2000), (1, 1), (513, 77), (64, 1025), (700, 0), (0, 300)])
 def test_bf2nn_parity(ctx, orc, na, nb, variant):
     from orbslam2_amd import _lib
@@ -105,7 +105,7 @@ def test_bf2nn_batch_many_pairs(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 22])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 22, 24])
 def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     """The vector-ALU kernel (11) and its tile-shape variants, the track-everything variant, the opt-in early-abandon
     variant (8: the last 64 bits of a comparison are skipped once the first 192 already reach the tracking bound), the
@@ -136,7 +136,7 @@ def test_bf2nn_kernel_variants_give_the_same_matches(ctx, orc, variant):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 12, 13, 14, 22])
+@pytest.mark.parametrize("variant", [0, 12, 13, 14, 22, 24])
 def test_bf2nn_tile_boundaries_mixed_sizes(ctx, orc, variant):
     """Frames of every size around the 32-row tile and the 128 / 256 / 512-row workgroup boundaries, mixed in ONE launch
     (a wave's number of live query tiles, the last candidate block and the rows between a frame's n and the stride all
@@ -252,7 +252,7 @@ def test_bf2nn_bench_size_properties(ctx, orc):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 17, 22])
+@pytest.mark.parametrize("variant", [0, 17, 22, 24])
 def test_bf2nn_every_distance_value_is_exact(ctx, orc, variant):
     """Every Hamming distance 0..256 through the matrix-core forms (distance = (256 - dot) / 2 of +-1 images; 22: the
     sign-free operands, result = distance + popcount(query) on top of the candidate row's popcount): for each d a
@@ -294,7 +294,7 @@ def test_bf2nn_every_distance_value_is_exact(ctx, orc, variant):
     ctx.free_frames(ids)
 
 
-@pytest.mark.parametrize("variant", [0, 17, 22])
+@pytest.mark.parametrize("variant", [0, 17, 22, 24])
 def test_bf2nn_extreme_popcounts(ctx, orc, variant):
     """Descriptors of every weight: all zeros, all ones, single bits, one zero bit, sparse and dense rows on both sides (in
     the sign-free form a result is distance + popcount(query) on top of popcount(candidate): 0 .. 768), 70 x 70 rows so
