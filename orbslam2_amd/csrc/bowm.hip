@@ -81,16 +81,32 @@ __device__ __forceinline__ int find_node(gptr<const uint32_t> nodes, int n, uint
 }
 
 // 32 descriptor bits -> 32 FP4 values (+1.0 = 0x2 for a 0 bit, -1.0 = 0xA for a 1 bit), eight per dword: dword k takes bits
-// 3 - k, 7 - k, ..., 31 - k, shifted up to the sign position of their nibble.  7 vector instructions (3 shifts + 4
-// v_and_or_b32; written as asm because the compiler otherwise spends 11: shift, and, or).
-__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask, uint32_t bits) {
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
+// 3 - k, 7 - k, ..., 31 - k, shifted up to the sign position of their nibble (3 shifts + 4 v_and_or_b32 per 32 bits).
+// Here for TWO dwords that sit in a register pair: one v_lshlrev_b64 shifts both (4.3 cycles per wave against 4.1 for each
+// v_lshlrev_b32, scripts/ubench_valu5.hip).  The bits that cross from the low into the high dword land at positions 0 .. 2,
+// which the sign mask drops.  12 + 32 instead of 24 + 32 vector instructions per tile.
+template <int S>
+__device__ __forceinline__ uint64_t shl64(uint64_t x) {
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, %1, %2" : "=v"(r) : "n"(S), "v"(x));
     return r;
 }
-__device__ __forceinline__ v8i expand_fp4(uint32_t w, uint32_t ones) {
-    const uint32_t sign = 0x88888888u;
-    return (v8i){(int)and_or(w << 3, sign, ones), (int)and_or(w << 2, sign, ones), (int)and_or(w << 1, sign, ones), (int)and_or(w, sign, ones), 0, 0, 0, 0};
+// The last step is written in C on purpose: (x & sign) | ones is ONE v_and_or_b32 either way, but an asm statement is not a
+// vector instruction to hipcc, and a matrix instruction needs two wait states after a vector write of one of its operands
+// (no hardware interlock: with one, the first passes of the product read the register's OLD contents -- seen as missing
+// matches in rows 0-11 of a tile).  hipcc inserts them for instructions it knows.
+__device__ __forceinline__ uint32_t and_or_c(uint32_t x, uint32_t bits) { return (x & 0x88888888u) | bits; }
+__device__ __forceinline__ void expand_fp4x2(uint64_t w, uint32_t ones, v8i &f0, v8i &f1) {
+    const uint64_t t3 = shl64<3>(w), t2 = shl64<2>(w), t1 = shl64<1>(w);
+    f0 = (v8i){(int)and_or_c((uint32_t)t3, ones), (int)and_or_c((uint32_t)t2, ones), (int)and_or_c((uint32_t)t1, ones), (int)and_or_c((uint32_t)w, ones), 0, 0, 0, 0};
+    f1 = (v8i){(int)and_or_c((uint32_t)(t3 >> 32), ones), (int)and_or_c((uint32_t)(t2 >> 32), ones), (int)and_or_c((uint32_t)(t1 >> 32), ones), (int)and_or_c((uint32_t)(w >> 32), ones), 0, 0, 0, 0};
+}
+
+// a wave-uniform address, said so that the compiler keeps it in scalar registers (and the per-lane part a 32-bit offset of the load)
+__device__ __forceinline__ gptr<const char> uniform_ptr(gptr<const char> p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (gptr<const char>)((uint64_t)lo | ((uint64_t)hi << 32));
 }
 
 // MODE 0: a7 (KF -> F), 1: a8 (KF -> KF), 2: a9 (SearchForTriangulation, ORBmatcher.cc:868-1093: no ratio test and no claims --
@@ -140,6 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
     asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
+    const uint32_t lane_off = (uint32_t)(32 * col + 16 * h);
     uint32_t *list = s_list[wave];
     uint8_t *tags = s_tags[wave];
     int my_matches = 0;
@@ -304,8 +321,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         auto request = [&](const TileDesc &d, v4u &xq, v4u &xc) {
             // a tile that starts near a node's end reads on into the next node's rows (the image ends with 32 spare rows); they
             // multiply as 0.0, see `live` below
-            xq = rowsA[2 * (size_t)(d.offA + d.qa0 + (uint32_t)col) + h];
-            xc = rowsB[2 * (size_t)(d.offB + d.cb0 + (uint32_t)col) + h];
+            // (the tile's first row is wave-uniform: it moves the base on the scalar unit, and the lane's own 32 col + 16 h
+            // bytes are one loop-invariant register -- no vector address arithmetic per tile)
+            xq = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsA + 2 * (size_t)(d.offA + d.qa0))) + lane_off);
+            xc = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsB + 2 * (size_t)(d.offB + d.cb0))) + lane_off);
         };
 
         // ---- the claims, on the records alone.  Records wait in the wave's list (a node's records are consecutive there)
@@ -440,18 +459,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         int node_start = 0, n_rec = 0;                        // records of finished nodes waiting in the list / records so far
         while (have) {
             const TileDesc D = ND;
-            const v4u xq = nxq, xc = nxc;
-            have = fetch(ND);
-            if (have) request(ND, nxq, nxc);
             const uint32_t nAs = D.nA, nBs = D.nB, qa0 = D.qa0, cb0 = D.cb0;
             {
                 v16f acc = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                const uint32_t wq[4] = {xq.x, xq.y, xq.z, xq.w}, wc[4] = {xc.x, xc.y, xc.z, xc.w};
+                const uint32_t wq[4] = {nxq.x, nxq.y, nxq.z, nxq.w}, wc[4] = {nxc.x, nxc.y, nxc.z, nxc.w};
                 // a row past the node's end multiplies as 0.0 everywhere (not as the +1.0 its zero bits would expand to): its
                 // dots are 0 = distance 128, never below capd, so no record can name a row that does not exist
                 const uint32_t liveq = qa0 + (uint32_t)col < nAs ? ones : 0u, livec = cb0 + (uint32_t)col < nBs ? ones : 0u;
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(expand_fp4(wc[s], livec), expand_fp4(wq[s], liveq), acc, 4, 4, 0, 0, 0, 0);   // zero scale operands select the unscaled encoding (one 8-byte instruction)
+                for (int s = 0; s < 4; s += 2) {
+                    v8i fc0, fc1, fq0, fq1;
+                    expand_fp4x2((uint64_t)wc[s] | ((uint64_t)wc[s + 1] << 32), livec, fc0, fc1);
+                    expand_fp4x2((uint64_t)wq[s] | ((uint64_t)wq[s + 1] << 32), liveq, fq0, fq1);
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fc0, fq0, acc, 4, 4, 0, 0, 0, 0);   // zero scale operands select the unscaled encoding (one 8-byte instruction)
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fc1, fq1, acc, 4, 4, 0, 0, 0, 0);
+                }
+                // the next tile's rows are requested into the registers this tile's rows have just left (no second register set
+                // and no copies: the loads fly under this tile's products and fold and under the other five waves of the SIMD)
+                have = fetch(ND);
+                if (have) request(ND, nxq, nxc);
                 // folded as integers (Tf >= 0: a positive float orders like its bits, a negative one is a negative integer):
                 // v_max3_i32 takes MFMA results as they are, fmaxf canonicalises each one first
                 int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
