@@ -495,15 +495,20 @@ __global__ __launch_bounds__(256) void bf2nn_mfma4_kernel(const FrameDev *__rest
 // col, one coalesced 1 KB read per 32 rows) and become FP4 +-1 values in registers (3 shifts + 4 v_and_or_b32 per 32 bits,
 // as in bowm.hip; the order of the 256 bit positions inside the product is free as long as both operands use the same one).
 // No staging instructions, no barrier, a quarter of the operand bytes; 28 more vector instructions per 32 candidate rows.
-__device__ __forceinline__ uint32_t bf_and_or(uint32_t x, uint32_t mask, uint32_t bits) {
+// The shift is an asm statement (hipcc would otherwise turn (w << k) & sign into (w & m) << k and spend an instruction more);
+// the and-or is C ON PURPOSE: it is the instruction that writes a matrix operand, and a matrix instruction needs two wait
+// states after a vector write of one of its operands, which hipcc inserts only behind instructions it knows -- an asm
+// statement is not one (found in bowm.hip: with one wait state the first passes of the product read the OLD register).
+template <int S>
+__device__ __forceinline__ uint32_t bf_shl(uint32_t x) {
     uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(bits));
+    asm("v_lshlrev_b32 %0, %1, %2" : "=v"(r) : "n"(S), "v"(x));
     return r;
 }
+__device__ __forceinline__ uint32_t bf_and_or(uint32_t x, uint32_t bits) { return (x & 0x88888888u) | bits; }
 __device__ __forceinline__ v8i bf_expand_fp4(uint32_t w, uint32_t ones) {
-    const uint32_t sign = 0x88888888u;
-    return (v8i){(int)bf_and_or(w << 3, sign, ones), (int)bf_and_or(w << 2, sign, ones), (int)bf_and_or(w << 1, sign, ones),
-                 (int)bf_and_or(w, sign, ones), 0, 0, 0, 0};
+    return (v8i){(int)bf_and_or(bf_shl<3>(w), ones), (int)bf_and_or(bf_shl<2>(w), ones), (int)bf_and_or(bf_shl<1>(w), ones),
+                 (int)bf_and_or(w, ones), 0, 0, 0, 0};
 }
 
 // Operands without a sign (PIPE 2).  The chip holds 2.0-2.1 GHz on +-1 operands and 2.25-2.3 GHz on non-negative ones
