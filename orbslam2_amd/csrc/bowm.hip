@@ -38,6 +38,7 @@ constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
 constexpr int BM_LIST = 320;          // records a wave collects before it settles them (a node with more than 64 takes the generic loop)
 constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
+constexpr int TL_CAP = 128;           // tiles a wave lists before it multiplies them (a batch of 64 nodes with more takes several passes)
 constexpr int BIN_ROWS = 4096;        // match rows up to this length keep their matches' rotation bins in LDS for the filter pass
 #ifdef ORBM_DIAG
 __device__ int d_bowm_diag;   // timing only, WRONG results: 1 = records are dropped before they are settled, 2 = no records are made, 4 = accepted matches are not applied
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ uint32_t s_list[4][BM_LIST];
     __shared__ uint8_t s_tags[4][BM_LIST];      // which of the wave's current 64 nodes a record belongs to
     __shared__ uint32_t s_cand[4];              // candidates named by the records of the tile at hand, one bit each (zero between tiles)
+    __shared__ uint2 s_tiles[4][TL_CAP];        // the wave's tile list: two words per 32 x 32 tile (see the tile loop)
     __shared__ __align__(16) uint8_t s_bin[SPLIT ? 16 : BIN_ROWS];   // rotation bin of the match in row i of the pair's match row, 0xFF = none (rows < BIN_ROWS)
     __shared__ int hist[ORBM_HISTO_LENGTH];
     __shared__ int keep[3];
@@ -156,9 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
     asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
-    const uint32_t lane_off = (uint32_t)(32 * col + 16 * h);
-    uint32_t *list = s_list[wave];
-    uint8_t *tags = s_tags[wave];
+    // (LDS pointers with their address space spelled out: 32 bits each, where `uint32_t *` is a 64-bit generic pointer held in a register pair)
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+    typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
+    const lds_u32p list = (lds_u32p)s_list[wave];
+    const lds_u8p tags = (lds_u8p)s_tags[wave];
     int my_matches = 0;
 
     float F12[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -293,38 +297,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             generic_node((uint32_t)__builtin_amdgcn_readlane((int)offA, node), (uint32_t)__builtin_amdgcn_readlane((int)nA, node),
                          (uint32_t)__builtin_amdgcn_readlane((int)offB, node), (uint32_t)__builtin_amdgcn_readlane((int)nB, node));
         }
-        // ---- the 32 x 32 tiles of the remaining nodes, one after the other; the operands of the NEXT tile (two 16-byte
-        // loads per lane) are requested before the current one is multiplied.  All of this state is wave-uniform.
-        struct TileDesc { uint32_t nA, nB, offA, offB, qa0, cb0; int node; bool last; };
-        uint32_t s_nA = 0, s_nB = 0, s_offA = 0, s_offB = 0, s_qa0 = 0, s_cb0 = 0;
-        int s_node = 0;
-        bool in_node = false;
-        auto fetch = [&](TileDesc &d) -> bool {
-            if (in_node) {
-                s_cb0 += 32;
-                if (s_cb0 >= s_nB) { s_cb0 = 0; s_qa0 += 32; if (s_qa0 >= s_nA) in_node = false; }
-            }
-            if (!in_node) {
-                if (!todo) return false;
-                s_node = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                s_nA = (uint32_t)__builtin_amdgcn_readlane((int)nA, s_node); s_nB = (uint32_t)__builtin_amdgcn_readlane((int)nB, s_node);
-                s_offA = (uint32_t)__builtin_amdgcn_readlane((int)offA, s_node); s_offB = (uint32_t)__builtin_amdgcn_readlane((int)offB, s_node);
-                s_qa0 = 0; s_cb0 = 0; in_node = true;
-            }
-            d.nA = s_nA; d.nB = s_nB; d.offA = s_offA; d.offB = s_offB; d.qa0 = s_qa0; d.cb0 = s_cb0; d.node = s_node;
-            d.last = s_qa0 + 32 >= s_nA && s_cb0 + 32 >= s_nB;
-            return true;
+        // ---- the 32 x 32 tiles of the remaining nodes.  The lanes (one node each) first write the wave's TILE LIST into LDS:
+        // two words per tile -- first row of the query operand | live rows << 16 | node's lane << 22 | last tile of its
+        // node << 28, and first row of the candidate operand | live rows << 16 -- a node's tiles consecutive, query tiles
+        // outer, candidate tiles inner.  The loop over the list then has two scalars of state per tile (where a state
+        // machine over nodes, tile rows and tile columns kept some twenty, most of them in spill lanes), and the operands
+        // of the NEXT tile are requested as soon as the current tile's rows have been expanded.
+        uint2 *const tiles = s_tiles[wave];
+        // (the list's LDS address as a scalar: entries are read at a uniform address, one v_mov away from it)
+        typedef __attribute__((address_space(3))) const uint32_t *lds_u32;
+        const uint32_t tiles_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2 *)tiles);
+        auto entry = [&](uint32_t i) -> uint2 {
+            const lds_u32 q = (lds_u32)(uintptr_t)(tiles_lds + 8u * i);
+            return make_uint2(q[0], q[1]);
         };
+        uint32_t t_incl = ((todo >> lane) & 1ull) ? ((nA + 31) >> 5) * ((nB + 31) >> 5) : 0u;
+        const bool listed = t_incl != 0u;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)t_incl, dlt, 64);
+            if (lane >= dlt) t_incl += o;
+        }
+        const uint32_t t_total = (uint32_t)__builtin_amdgcn_readlane((int)t_incl, 63);
         // lane (col, h) takes 16-byte half h of row col: dword s of it feeds k step s, for queries and candidates alike (the
         // order of the 256 bit positions inside the product is free as long as both operands use the same one)
-        auto request = [&](const TileDesc &d, v4u &xq, v4u &xc) {
+        auto request = [&](uint32_t w0, uint32_t w1, v4u &xq, v4u &xc) {
             // a tile that starts near a node's end reads on into the next node's rows (the image ends with 32 spare rows); they
             // multiply as 0.0, see `live` below
             // (the tile's first row is wave-uniform: it moves the base on the scalar unit, and the lane's own 32 col + 16 h
             // bytes are one loop-invariant register -- no vector address arithmetic per tile)
-            xq = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsA + 2 * (size_t)(d.offA + d.qa0))) + lane_off);
-            xc = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsB + 2 * (size_t)(d.offB + d.cb0))) + lane_off);
+            // (the empty asm keeps the offset's zero-extension inside this block, where the instruction selector can fold it
+            // into the load: global_load_dwordx4 v, v_offset, s[base] -- hoisted out of the loop it becomes a 64-bit register
+            // pair and a 64-bit vector add per operand)
+            uint32_t lo32 = (uint32_t)threadIdx.x;
+            asm volatile("" : "+v"(lo32));
+            lo32 = ((lo32 & 31u) << 5) | ((lo32 >> 1) & 16u);        // 32 col + 16 h, made here: three instructions against a register held (or reloaded) across the loop
+            xq = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsA + 2 * (size_t)(w0 & 0xFFFFu))) + lo32);
+            xc = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsB + 2 * (size_t)(w1 & 0xFFFFu))) + lo32);
         };
 
         // ---- the claims, on the records alone.  Records wait in the wave's list (a node's records are consecutive there)
@@ -381,8 +390,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 // the lanes of my node: [first, last]
                 const int prev_tg = __shfl_up(tg, 1, 64);
                 const unsigned long long heads = __ballot(in && (lane == 0 || tg != prev_tg));
-                const int first = 63 - __builtin_clzll((heads & (~0ull >> (63 - lane))) | 1ull);
-                const unsigned long long later = lane < 63 ? (heads | (take < 64 ? 1ull << take : 0ull)) >> (lane + 1) : 0ull;
+                // (lane_r: the lane number again, opaque, so that the per-lane 64-bit masks below are made here and not kept in
+                // register pairs across the tile loop)
+                int lane_r = lane;
+                asm volatile("" : "+v"(lane_r));
+                const int first = 63 - __builtin_clzll((heads & (~0ull >> (63 - lane_r))) | 1ull);
+                const unsigned long long later = lane_r < 63 ? (heads | (take < 64 ? 1ull << take : 0ull)) >> (lane_r + 1) : 0ull;
                 const int last = later ? lane + __builtin_ctzll(later) : take - 1;
                 const int run = last - first + 1;
                 if (MODE == 2) {
@@ -452,20 +465,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             }
         };
 
-        TileDesc ND;
-        v4u nxq = {0, 0, 0, 0}, nxc = {0, 0, 0, 0};
-        bool have = fetch(ND);
-        if (have) request(ND, nxq, nxc);
         int node_start = 0, n_rec = 0;                        // records of finished nodes waiting in the list / records so far
-        while (have) {
-            const TileDesc D = ND;
-            const uint32_t nAs = D.nA, nBs = D.nB, qa0 = D.qa0, cb0 = D.cb0;
+        for (uint32_t t_base = 0; t_base < t_total; t_base += TL_CAP) {
+        const uint32_t t_cnt = min((uint32_t)TL_CAP, t_total - t_base);
+        {
+            // my node's tiles that fall into this pass
+            const uint32_t tBn = (nB + 31) >> 5;
+            const uint32_t t_excl = listed ? t_incl - ((nA + 31) >> 5) * tBn : t_incl;
+            const uint32_t k0 = max(t_excl, t_base), k1 = min(t_incl, t_base + t_cnt);
+            if (listed && k0 < k1) {
+                uint32_t ia = (k0 - t_excl) / tBn, ib = (k0 - t_excl) - ia * tBn;
+                for (uint32_t kk = k0; kk < k1; kk++) {
+                    const uint32_t qa0 = ia * 32u, cb0 = ib * 32u;
+                    tiles[kk - t_base] = make_uint2((offA + qa0) | (min(32u, nA - qa0) << 16) | ((uint32_t)lane << 22) | (kk + 1 == t_incl ? 1u << 28 : 0u),
+                                                    (offB + cb0) | (min(32u, nB - cb0) << 16));
+                    if (++ib == tBn) { ib = 0; ia++; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the list is read by every lane
+            __builtin_amdgcn_wave_barrier();
+        }
+        v4u nxq = {0, 0, 0, 0}, nxc = {0, 0, 0, 0};
+        uint32_t nw0, nw1;
+        {
+            const uint2 e = entry(0);
+            nw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); nw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+            request(nw0, nw1, nxq, nxc);
+        }
+        for (uint32_t ti = 0; ti < t_cnt; ti++) {
+            const uint32_t cw0 = nw0, cw1 = nw1;
+            const int d_node = (int)((cw0 >> 22) & 63u);
+            const bool d_last = (cw0 >> 28) & 1u;
             {
                 v16f acc = (v16f){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 const uint32_t wq[4] = {nxq.x, nxq.y, nxq.z, nxq.w}, wc[4] = {nxc.x, nxc.y, nxc.z, nxc.w};
                 // a row past the node's end multiplies as 0.0 everywhere (not as the +1.0 its zero bits would expand to): its
                 // dots are 0 = distance 128, never below capd, so no record can name a row that does not exist
-                const uint32_t liveq = qa0 + (uint32_t)col < nAs ? ones : 0u, livec = cb0 + (uint32_t)col < nBs ? ones : 0u;
+                const uint32_t liveq = (uint32_t)col < ((cw0 >> 16) & 63u) ? ones : 0u, livec = (uint32_t)col < ((cw1 >> 16) & 63u) ? ones : 0u;
 #pragma unroll
                 for (int s = 0; s < 4; s += 2) {
                     v8i fc0, fc1, fq0, fq1;
@@ -476,8 +512,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 }
                 // the next tile's rows are requested into the registers this tile's rows have just left (no second register set
                 // and no copies: the loads fly under this tile's products and fold and under the other five waves of the SIMD)
-                have = fetch(ND);
-                if (have) request(ND, nxq, nxc);
+                if (ti + 1 < t_cnt) {
+                    const uint2 en = entry(ti + 1);
+                    nw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.x); nw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)en.y);
+                    request(nw0, nw1, nxq, nxc);
+                }
                 // folded as integers (Tf >= 0: a positive float orders like its bits, a negative one is a negative integer):
                 // v_max3_i32 takes MFMA results as they are, fmaxf canonicalises each one first
                 int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
@@ -486,6 +525,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 m = max(m, __float_as_int(acc[15]));
                 if (!BOWM_DIAG(2) && __any(m > Ti)) {
                     // the lane holds query qa0 + col against candidates cb0 + (r & 3) + 8 (r >> 2) + 4 h
+                    const uint32_t qa0 = (cw0 & 0xFFFFu) - (uint32_t)__builtin_amdgcn_readlane((int)offA, d_node);
+                    const uint32_t cb0 = (cw1 & 0xFFFFu) - (uint32_t)__builtin_amdgcn_readlane((int)offB, d_node);
                     const uint32_t qbits = (qa0 + (uint32_t)col) << 20, t0 = cb0 + (uint32_t)(4 * h);
                     const bool hitl = m > Ti;
                     const unsigned long long hm_all = __ballot(hitl);
@@ -507,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                         for (int r = 1; r < 16; r++) code = hr[r] ? (uint32_t)((r & 3) + 8 * (r >> 2)) : code;
                         const uint32_t d13 = (uint32_t)(256 - (int)__int_as_float(m)) << 12;     // distance << 13 (the dot is even)
                         const int pos = n_rec + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm_all >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm_all, 0u));
-                        if (hitl && pos < BM_LIST) { list[pos] = (qbits | d13) + (t0 + code); tags[pos] = (uint8_t)D.node; }
+                        if (hitl && pos < BM_LIST) { list[pos] = (qbits | d13) + (t0 + code); tags[pos] = (uint8_t)d_node; }
                         n_rec += nhit;
                         // two records of this tile with one query (its two lanes) or one candidate (the bit was set before)?
                         const uint32_t bit = 1u << (code + (uint32_t)(4 * h));
@@ -526,29 +567,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                             if (!hm) continue;
                             if (hr[r]) {
                                 const uint32_t d = (uint32_t)((256 - (int)acc[r]) >> 1);
-                                const int pos = n_rec + (int)__popcll(hm & ((1ull << lane) - 1ull));   // the wave counts its own records
-                                if (pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + (uint32_t)((r & 3) + 8 * (r >> 2))); tags[pos] = (uint8_t)D.node; }
+                                const int pos = n_rec + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));   // the wave counts its own records (mbcnt: no per-lane 64-bit mask to keep in registers)
+                                if (pos < BM_LIST) { list[pos] = qbits | (d << 13) | (t0 + (uint32_t)((r & 3) + 8 * (r >> 2))); tags[pos] = (uint8_t)d_node; }
                             }
                             n_rec += (int)__popcll(hm);
                         }
                     }
                 }
             }
-            if (!D.last) continue;
+            if (!d_last) continue;
             const bool was_contested = node_contested;
             node_contested = false; node_tiles_hit = 0;
             if (n_rec - node_start > 64) {
                 // more relevant pairs than lanes: this node takes the generic loop, its records are dropped
-                generic_node(D.offA, nAs, D.offB, nBs);
+                generic_node((uint32_t)__builtin_amdgcn_readlane((int)offA, d_node), (uint32_t)__builtin_amdgcn_readlane((int)nA, d_node),
+                             (uint32_t)__builtin_amdgcn_readlane((int)offB, d_node), (uint32_t)__builtin_amdgcn_readlane((int)nB, d_node));
                 n_rec = node_start;
             } else {
-                if (!was_contested) simple_nodes |= 1ull << D.node;
+                if (!was_contested) simple_nodes |= 1ull << d_node;
                 node_start = n_rec;
             }
             if (node_start > BM_LIST - 64) {                   // the next node may need 64 slots
                 resolve(node_start);
                 node_start = 0; n_rec = 0;
             }
+        }
+        __builtin_amdgcn_wave_barrier();                      // (the list is rewritten by the next pass)
         }
         BOWM_STAMP(3);
         resolve(node_start);                                  // before the lanes' node table moves on to the next 64 nodes
