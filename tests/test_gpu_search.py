@@ -135,6 +135,45 @@ def test_bow_kernel_forms_are_all_exact(ctx, orc, form):
         L.orbm__bow_split_below(2048)
 
 
+def test_bow_tile_list_passes(ctx, orc):
+    """The matrix-core form lists a wave's 32 x 32 tiles in LDS, 128 at a time: frames whose nodes need many more (a single
+    node of 1500 x 1500 features = 2209 tiles, 18 passes of one wave) and nodes of very unequal size side by side, so that a
+    node's tiles straddle the end of a pass and the last entry of a pass is not the last tile of its node.  Both kinds,
+    split and whole-pair launches, the rotation filter on."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4242)
+    lm_desc = synth.random_descriptors(rng, 400)
+    def frame(n, node_sizes):
+        lm = rng.integers(0, len(lm_desc), n)
+        flags = np.where(rng.random(n) < 0.9, MP_PRESENT | MP_OBS, 0).astype(np.uint8)
+        f = synth.make_frame(rng, lm_desc, lm, mp_flags=flags, p_flip=0.04, n_nodes=1, octave=rng.integers(0, 8, n).astype(np.int32))
+        node = np.repeat(np.arange(len(node_sizes)) * 4, node_sizes)[:n]      # node ids 0, 4, 8, ...: every one lands in wave 0 .. 3 by its index, not its id
+        node = np.concatenate([node, np.full(n - len(node), node[-1])]) if len(node) < n else node
+        f.fv_node, f.fv_off, f.fv_idx = synth.feature_vector(rng.permutation(node))
+        return f
+    kfs = [frame(1500, [1500]), frame(1400, [1400]),                                   # one node each: 47 x 44 tiles in one wave
+           frame(1500, [700, 33, 5, 600, 1, 161]), frame(1300, [650, 40, 7, 500, 3, 100]),   # 22 x 21 = 462 tiles, then 2 x 2, 1, 19 x 16, 1, 6 x 4
+           frame(900, [31] * 29 + [1]), frame(950, [33] * 28 + [26])]                  # many small nodes: 1 tile against 2 x 2 per node
+    ids = ctx.upload_frames(kfs)
+    pa, pb = np.meshgrid(np.arange(len(kfs)), np.arange(len(kfs)))
+    pa, pb = pa.ravel(), pb.ravel()
+    try:
+        L.orbm__bow_variant(5)
+        for split_below in (1, 4096):                                  # whole pairs / pairs split over workgroups
+            L.orbm__bow_split_below(split_below)
+            for variant in (0, 1):
+                counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=1500)
+                for k in range(len(pa)):
+                    wc, wm, _ = orc.search_bow(variant, kfs[pa[k]], kfs[pb[k]], 0.75, True)
+                    assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (split_below, variant, pa[k], pb[k])
+        assert sum(orc.search_bow(1, kfs[i], kfs[i + 1], 0.75, True)[0] for i in (0, 2, 4)) > 100
+    finally:
+        L.orbm__bow_variant(0)
+        L.orbm__bow_split_below(2048)
+    ctx.free_frames(ids)
+
+
 @pytest.mark.parametrize("ratio", [0.3, 0.6, 0.9, 1.0, 1.5])
 def test_bow_matrix_core_form_ratios(ctx, orc, ratio):
     """The matrix-core form only looks at distances below a bound derived from the ratio (67 for 0.75, 84 for 0.6, 51 for
