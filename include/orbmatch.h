@@ -245,7 +245,11 @@ int orbm_distinctive_descriptors_batch(orbm_ctx *ctx, int n_points, const int32_
  * The distances are computed on the matrix cores (every descriptor bit as +-1 in FP4, expanded in registers from the
  * frames' raw rows; exact) and are identical to the xor + popcount form, which the environment variable
  * ORBMATCH_BF2NN_KERNEL=valu selects instead.  ORBMATCH_BF2NN_KERNEL=lds selects round 1's form of the same product, which
- * keeps a pre-expanded image of each frame (128 B per descriptor, built on the device the first time a frame is used). */
+ * keeps a pre-expanded image of each frame (128 B per descriptor, built on the device the first time a frame is used).
+ * Large batches (about a thousand 2000 x 2000 pairs and more) that ask for matches only (best_d == second_d == NULL)
+ * under an acceptance rule whose bound stays below 73 (th 50 at ratio 0.75: 67) multiply the last 64 bits of a comparison
+ * only for blocks of 32 candidates in which some 192-bit partial distance is already below its bound (identical matches,
+ * about a fifth faster); ORBMATCH_BF2NN_KERNEL=full multiplies every bit of every comparison regardless. */
 int orbm_bf2nn_batch(orbm_ctx *ctx, int n_pairs, const int32_t *frame_a, const int32_t *frame_b,
                      float ratio, int th, int32_t stride, int32_t *match, int32_t *best_d,
                      int32_t *second_d, int32_t *counts, int io_on_device);

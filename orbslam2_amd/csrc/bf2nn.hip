@@ -811,7 +811,7 @@ static int bf2nn_variant_in_use() {
     static const bool env_early_abandon = [] { const char *e = getenv("ORBMATCH_BF2NN_EARLY_ABANDON"); return e && e[0] == '1'; }();
     // ORBMATCH_BF2NN_KERNEL=valu selects the vector-ALU xor + popcount kernel (no +-1 image of the frames is built)
     static const bool env_valu = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return e && !strcmp(e, "valu"); }();
-    static const int env_form = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return !e ? 0 : !strcmp(e, "lds") ? 10 : !strcmp(e, "raw2") ? 12 : !strcmp(e, "raw4") ? 13 : 0; }();
+    static const int env_form = [] { const char *e = getenv("ORBMATCH_BF2NN_KERNEL"); return !e ? 0 : !strcmp(e, "lds") ? 10 : !strcmp(e, "raw2") ? 12 : !strcmp(e, "raw4") ? 13 : !strcmp(e, "full") ? 22 : 0; }();      // full: every bit of every comparison multiplied (no deferred last 64 bits)
     return g_bf_variant != 0 ? g_bf_variant : env_early_abandon ? 8 : env_valu ? 11 : env_form ? env_form : 15;
 }
 
