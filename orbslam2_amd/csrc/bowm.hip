@@ -38,6 +38,9 @@ constexpr uint32_t INITKEY = (256u << 16) | 0xFFFFu;
 constexpr int MAX_N = 65536;
 constexpr int BM_LIST = 320;          // records a wave collects before it settles them (a node with more than 64 takes the generic loop)
 constexpr uint32_t REC_MAX_Q = 4096, REC_MAX_T = 8192;   // record = q << 20 | d << 13 | t
+// waves per SIMD: five (96 registers).  Six (80) were better while the tile loop waited on loads (round 3's first half: + 6 %);
+// the loop of the tile list is bound by vector issue, six waves spill into it, and five are 3-5 % faster on pairs with matches
+#define BOWM_WAVES 5
 constexpr int TL_CAP = 128;           // tiles a wave lists before it multiplies them (a batch of 64 nodes with more takes several passes)
 constexpr int BIN_ROWS = 4096;        // match rows up to this length keep their matches' rotation bins in LDS for the filter pass
 #ifdef ORBM_DIAG
@@ -117,7 +120,7 @@ __device__ __forceinline__ gptr<const char> uniform_ptr(gptr<const char> p) {
 // batches: a single SearchByBoW call would otherwise run on one CU); the match rows were pre-set to -1 by the caller, histogram
 // and count go to pair_acc (32 ints per pair) and bow_finish_kernel (bow.hip) applies the rotation filter afterwards.
 template <int MODE, bool SPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOWM_WAVES, BOWM_WAVES))) void bowm_kernel(const FrameDev *__restrict__ table, const int32_t *__restrict__ fa,
                                                    const int32_t *__restrict__ fb, float ratio, int capd, int check_ori, int stride,
                                                    int32_t *__restrict__ match_all, int32_t *__restrict__ counts, int splits,
                                                    int *__restrict__ pair_acc, int only_stereo, const float *__restrict__ f12all,
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t ones = 0x22222222u;                                       // +1.0 in every nibble, kept in a vector register
     asm volatile("" : "+v"(ones));
     const gptr<const v4u> rowsA = (gptr<const v4u>)A.descfv, rowsB = (gptr<const v4u>)B.descfv;   // FeatureVector order
+    const uint32_t lane_off = (uint32_t)(32 * col + 16 * h);
     // (LDS pointers with their address space spelled out: 32 bits each, where `uint32_t *` is a 64-bit generic pointer held in a register pair)
     typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
     typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
@@ -329,9 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             // (the empty asm keeps the offset's zero-extension inside this block, where the instruction selector can fold it
             // into the load: global_load_dwordx4 v, v_offset, s[base] -- hoisted out of the loop it becomes a 64-bit register
             // pair and a 64-bit vector add per operand)
-            uint32_t lo32 = (uint32_t)threadIdx.x;
+            uint32_t lo32 = lane_off;                                 // 32 col + 16 h
             asm volatile("" : "+v"(lo32));
-            lo32 = ((lo32 & 31u) << 5) | ((lo32 >> 1) & 16u);        // 32 col + 16 h, made here: three instructions against a register held (or reloaded) across the loop
             xq = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsA + 2 * (size_t)(w0 & 0xFFFFu))) + lo32);
             xc = *(gptr<const v4u>)(uniform_ptr((gptr<const char>)(rowsB + 2 * (size_t)(w1 & 0xFFFFu))) + lo32);
         };
