@@ -188,6 +188,20 @@ def test_release_library_exports_no_result_changing_knob():
     assert b"ORBM_MFMA_DIAG" not in blob
 
 
+def test_no_asm_statement_writes_a_matrix_operand():
+    """A matrix instruction needs two wait states after a vector write of one of its operands, and hipcc inserts them only
+    behind instructions it knows: an `asm` statement that writes an FP4 fragment is a hazard the compiler cannot see (it
+    lost a tenth of the matches of a SearchByBoW launch once).  In the kernels that feed MFMAs from registers
+    the and-or that finishes a fragment must be C; only shifts may be `asm`."""
+    import re
+    for f in ("bowm.hip", "bf2nn.hip"):
+        src = open(os.path.join(ROOT, "orbslam2_amd", "csrc", f)).read()
+        for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"([^"]*)"', src):
+            text = m.group(1)
+            # (v_bcnt_u32_b32: the popcount chain of the vector-ALU kernel, which multiplies nothing)
+            assert text == "" or text.startswith(("v_lshlrev_b64", "v_lshlrev_b32", "s_setprio", "v_bcnt_u32_b32")), (f, text)
+
+
 def _overflow_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
