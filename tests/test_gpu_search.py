@@ -174,6 +174,33 @@ def test_bow_tile_list_passes(ctx, orc):
     ctx.free_frames(ids)
 
 
+def test_bow_largest_frames(ctx, orc):
+    """Frames at the size limit (65535 keypoints: the largest row index a tile-list entry has to hold) against a large and a
+    small one, nodes of ~1000 rows (tile lists of ~1000 entries per node, many passes), both kinds, the matrix-core form."""
+    from orbslam2_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(65535)
+    lm_desc = synth.random_descriptors(rng, 30000)
+    def frame(n, n_nodes):
+        lm = rng.integers(0, len(lm_desc), n)
+        flags = np.where(rng.random(n) < 0.8, MP_PRESENT | MP_OBS, 0).astype(np.uint8)
+        return synth.make_frame(rng, lm_desc, lm, mp_flags=flags, p_flip=0.05, n_nodes=n_nodes, node_noise=0.02, octave=rng.integers(0, 8, n).astype(np.int32))
+    kfs = [frame(65535, 64), frame(40000, 64), frame(700, 64)]
+    ids = ctx.upload_frames(kfs)
+    try:
+        L.orbm__bow_variant(5)
+        for variant in (0, 1):
+            pa = np.array([0, 1, 0, 2]); pb = np.array([1, 0, 2, 0])
+            counts, match = ctx.search_bow(variant, ids[pa], ids[pb], 0.75, True, stride=65535)
+            for k in range(len(pa)):
+                wc, wm, _ = orc.search_bow(variant, kfs[pa[k]], kfs[pb[k]], 0.75, True)
+                assert counts[k] == wc and np.array_equal(match[k, :len(wm)], wm), (variant, pa[k], pb[k])
+                assert k > 1 or wc > 1000
+    finally:
+        L.orbm__bow_variant(0)
+    ctx.free_frames(ids)
+
+
 @pytest.mark.parametrize("ratio", [0.3, 0.6, 0.9, 1.0, 1.5])
 def test_bow_matrix_core_form_ratios(ctx, orc, ratio):
     """The matrix-core form only looks at distances below a bound derived from the ratio (67 for 0.75, 84 for 0.6, 51 for
