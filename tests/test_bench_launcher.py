@@ -48,3 +48,25 @@ def test_roofline_traffic_comes_from_a_counter_pass_on_the_same_workload():
     assert 1e7 < rec["hbm_bytes_per_launch"] < 5e9
     assert bench.measured_traffic(640, bench.PAIRS_PER_LAUNCH) is None
     assert bench.measured_traffic(bench.STORE_KF, 4096) is None
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The lines kept under profiles/ (the trace run and the unprofiled run of the default command) carry what the driver reads:
+    metric / value / unit, roofline with bound, achieved, peak, frac and a measured traffic figure, cpu_baseline with cores and
+    kind -- and the headline kernel is the form that multiplies every bit of every comparison; the deferred default stands
+    beside it without a fraction of the MFMA peak."""
+    import json
+    for name in ("r03_bench_line.json", "r03_bench_line_unprofiled.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["metric"].startswith("G Hamming cmps/s") and d["unit"] == "G Hamming cmps/s" and d["n_gpus"] == 1
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["kernel"] == "bf2nn_mfma4r_kernel<false,4,2>" and r["traffic"] and r["traffic_source"].startswith("profiles/")
+        # value is whole-job throughput, the kernel's own rate can only be higher
+        assert d["value"] <= r["achieved_T_cmps_per_s"] * 1e3 * 1.001
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+        f = d["roofline_deferred_form"]
+        assert f["kernel"] == "bf2nn_mfma4r_kernel<false,4,4>" and "frac" not in f and f["vs_headline_form"] > 1.0
